@@ -1,0 +1,212 @@
+"""TensorFlow-free reader for TF "V2 checkpoint" tensor bundles.
+
+The reference restores weights with ``tf.train.Saver.restore`` (helper/tf_graph.py:263-280)
+from ``models/<name>.ckpt.{index,data-00000-of-00001}``.  TensorFlow is not part of this stack,
+so the two files are parsed directly:
+
+* ``.index``  -- a LevelDB-style sorted table.  48-byte footer = two block handles
+  (metaindex, index; each ``varint64 offset, varint64 size``), zero padding, and the 8-byte magic
+  ``0xdb4775248b80fb57``.  A block is a run of prefix-compressed entries
+  (``varint shared, varint non_shared, varint value_len, key_suffix, value``) followed by a
+  restart array ``uint32[n], uint32 n``; on disk every block is trailed by a 1-byte compression
+  tag (0 = raw, the only kind the reference's checkpoints use) and a 4-byte CRC.
+  Index-block values are handles of data blocks; data-block keys are variable names and values
+  are serialized ``BundleEntryProto`` messages.  The key ``""`` holds the ``BundleHeaderProto``.
+* ``.data-00000-of-00001`` -- raw little-endian tensors at ``[offset, offset + size)``.
+
+Only what the DCSCN checkpoints contain is supported: float32 tensors, a single shard,
+uncompressed blocks.  Anything else raises ``CheckpointError`` (never silently mis-reads).
+"""
+
+import os
+import struct
+
+import numpy as np
+
+_TABLE_MAGIC = 0xDB4775248B80FB57
+_FOOTER_LEN = 48
+_DT_FLOAT = 1
+
+
+class CheckpointError(Exception):
+    pass
+
+
+def _varint(buf, pos):
+    result = 0
+    shift = 0
+    while True:
+        if pos >= len(buf):
+            raise CheckpointError("truncated varint")
+        byte = buf[pos]
+        pos += 1
+        result |= (byte & 0x7F) << shift
+        if not byte & 0x80:
+            return result, pos
+        shift += 7
+        if shift > 63:
+            raise CheckpointError("varint too long")
+
+
+def _block_entries(buf, offset, size):
+    """Yield (key, value) from one table block (without its 5-byte trailer)."""
+    if offset + size + 5 > len(buf):
+        raise CheckpointError("block handle outside file")
+    if buf[offset + size] != 0:
+        raise CheckpointError("compressed table blocks are not supported")
+    block = buf[offset:offset + size]
+    if size < 4:
+        raise CheckpointError("block too small")
+    n_restarts = struct.unpack_from("<I", block, size - 4)[0]
+    limit = size - 4 - 4 * n_restarts
+    if limit < 0:
+        raise CheckpointError("corrupt restart array")
+    pos = 0
+    key = b""
+    while pos < limit:
+        shared, pos = _varint(block, pos)
+        non_shared, pos = _varint(block, pos)
+        value_len, pos = _varint(block, pos)
+        key = key[:shared] + bytes(block[pos:pos + non_shared])
+        pos += non_shared
+        value = bytes(block[pos:pos + value_len])
+        pos += value_len
+        yield key, value
+
+
+def _proto_fields(buf):
+    """Minimal protobuf wire-format walker: yields (field_number, wire_type, value)."""
+    pos = 0
+    while pos < len(buf):
+        tag, pos = _varint(buf, pos)
+        field, wire = tag >> 3, tag & 7
+        if wire == 0:
+            value, pos = _varint(buf, pos)
+        elif wire == 1:
+            value = buf[pos:pos + 8]
+            pos += 8
+        elif wire == 2:
+            length, pos = _varint(buf, pos)
+            value = buf[pos:pos + length]
+            pos += length
+        elif wire == 5:
+            value = buf[pos:pos + 4]
+            pos += 4
+        else:
+            raise CheckpointError("unsupported protobuf wire type %d" % wire)
+        yield field, wire, value
+
+
+def _parse_shape(buf):
+    dims = []
+    for field, wire, value in _proto_fields(buf):
+        if field == 2 and wire == 2:          # TensorShapeProto.dim
+            size = 0
+            for f2, w2, v2 in _proto_fields(value):
+                if f2 == 1 and w2 == 0:       # Dim.size
+                    size = v2
+            dims.append(size)
+        elif field == 3 and wire == 0 and value:
+            raise CheckpointError("unknown-rank shapes are not supported")
+    return tuple(dims)
+
+
+def _parse_entry(buf):
+    entry = {"dtype": 0, "shape": (), "shard": 0, "offset": 0, "size": 0, "sliced": False}
+    for field, wire, value in _proto_fields(buf):
+        if field == 1 and wire == 0:
+            entry["dtype"] = value
+        elif field == 2 and wire == 2:
+            entry["shape"] = _parse_shape(value)
+        elif field == 3 and wire == 0:
+            entry["shard"] = value
+        elif field == 4 and wire == 0:
+            entry["offset"] = value
+        elif field == 5 and wire == 0:
+            entry["size"] = value
+        elif field == 7:
+            entry["sliced"] = True
+    return entry
+
+
+def read_index(index_path):
+    """Return ``{variable_name: entry_dict}`` for a ``<prefix>.index`` file."""
+    with open(index_path, "rb") as f:
+        buf = f.read()
+    if len(buf) < _FOOTER_LEN:
+        raise CheckpointError("index file too small: %s" % index_path)
+    footer = buf[-_FOOTER_LEN:]
+    if struct.unpack_from("<Q", footer, _FOOTER_LEN - 8)[0] != _TABLE_MAGIC:
+        raise CheckpointError("bad table magic in %s" % index_path)
+    pos = 0
+    _, pos = _varint(footer, pos)            # metaindex offset
+    _, pos = _varint(footer, pos)            # metaindex size
+    index_off, pos = _varint(footer, pos)
+    index_size, pos = _varint(footer, pos)
+
+    entries = {}
+    num_shards = None
+    for _, handle in _block_entries(buf, index_off, index_size):
+        block_off, hpos = _varint(handle, 0)
+        block_size, hpos = _varint(handle, hpos)
+        for key, value in _block_entries(buf, block_off, block_size):
+            if key == b"":
+                for field, wire, v in _proto_fields(value):   # BundleHeaderProto
+                    if field == 1 and wire == 0:
+                        num_shards = v
+                    elif field == 2 and wire == 0 and v != 0:
+                        raise CheckpointError("big-endian bundles are not supported")
+                continue
+            entries[key.decode("utf-8")] = _parse_entry(value)
+    if num_shards not in (None, 1):
+        raise CheckpointError("multi-shard bundles are not supported (num_shards=%s)" % num_shards)
+    return entries
+
+
+def list_variables(prefix):
+    """``[(name, shape)]`` of every variable in the checkpoint ``prefix`` (sorted by name)."""
+    entries = read_index(prefix + ".index")
+    return [(name, entries[name]["shape"]) for name in sorted(entries)]
+
+
+def has_data(prefix):
+    return os.path.isfile(prefix + ".data-00000-of-00001")
+
+
+def load_checkpoint(prefix, include_optimizer_slots=False):
+    """Load every float32 variable of ``<prefix>.index`` / ``.data-00000-of-00001``.
+
+    Adam slot variables (``.../Adam``, ``.../Adam_1``, ``beta1_power``, ``beta2_power``) written by
+    the reference's training graph are dropped unless ``include_optimizer_slots``.
+    """
+    entries = read_index(prefix + ".index")
+    data_path = prefix + ".data-00000-of-00001"
+    if not os.path.isfile(data_path):
+        raise CheckpointError("checkpoint data shard missing: %s" % data_path)
+    with open(data_path, "rb") as f:
+        blob = f.read()
+
+    tensors = {}
+    for name, entry in entries.items():
+        if not include_optimizer_slots and is_optimizer_slot(name):
+            continue
+        if entry["sliced"]:
+            raise CheckpointError("partitioned variable %s is not supported" % name)
+        if entry["dtype"] != _DT_FLOAT:
+            if is_optimizer_slot(name):
+                continue
+            raise CheckpointError("variable %s has unsupported dtype enum %d" % (name, entry["dtype"]))
+        count = int(np.prod(entry["shape"], dtype=np.int64)) if entry["shape"] else 1
+        if entry["size"] != 4 * count:
+            raise CheckpointError("variable %s: size %d does not match shape %s"
+                                  % (name, entry["size"], entry["shape"]))
+        if entry["offset"] + entry["size"] > len(blob):
+            raise CheckpointError("variable %s lies outside the data shard" % name)
+        array = np.frombuffer(blob, dtype="<f4", count=count, offset=entry["offset"])
+        tensors[name] = array.reshape(entry["shape"]).astype(np.float32, copy=True)
+    return tensors
+
+
+def is_optimizer_slot(name):
+    leaf = name.rsplit("/", 1)[-1]
+    return leaf in ("Adam", "Adam_1") or name in ("beta1_power", "beta2_power")
