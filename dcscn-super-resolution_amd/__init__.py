@@ -1,0 +1,13 @@
+"""MI355X-native DCSCN super-resolution inference path.
+
+Host side (Python) of the drop-in for the forward pass of jiny2001/dcscn-super-resolution:
+
+  engine.py   ctypes binding of libdcscn_hip.so (the hand-written gfx950 kernels behind include/dcscn.h)
+  ckpt.py     TensorFlow-free reader of the reference's V2 checkpoints
+  build.py    hipcc build of the shared library
+
+The directory name is not a valid Python identifier; import it through the ``dcscn_amd`` alias module
+at the repository root (``import dcscn_amd``) or ``importlib.import_module("dcscn-super-resolution_amd")``.
+"""
+
+__all__ = ["build", "ckpt", "engine"]

@@ -1,0 +1,71 @@
+"""Builds libdcscn_hip.so (the C ABI of include/dcscn.h) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so sits next
+to this file and travels to the GPU box with the source tree.
+"""
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
+LIB_NAME = "libdcscn_hip.so"
+LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
+SOURCES = ["api.hip", "kernels.hip"]
+HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(INCLUDE, "dcscn.h")]
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.isfile(cand):
+            return cand
+    raise RuntimeError("hipcc not found; the DCSCN HIP extension cannot be built")
+
+
+def _stale(target, deps):
+    if not os.path.isfile(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("command failed (%d): %s\n%s" % (proc.returncode, " ".join(cmd), proc.stdout))
+    return proc.stdout
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libdcscn_hip.so. Returns the library path."""
+    hipcc = hipcc_path()
+    obj_dir = os.path.join(PKG_DIR, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        src_path = os.path.join(CSRC, src)
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src_path] + HEADERS):
+            jobs.append([hipcc] + FLAGS + ["-I", INCLUDE, "-c", src_path, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+            for out in pool.map(_run, jobs):
+                if verbose and out.strip():
+                    print(out, file=sys.stderr)
+    if jobs or force or _stale(LIB_PATH, objs):
+        out = _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", LIB_PATH])
+        if verbose and out.strip():
+            print(out, file=sys.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,1024 @@
+// C ABI (include/dcscn.h) and execution plan of the DCSCN forward pass on one MI355X.
+//
+// dcscn_create restates SuperResolution.build_graph (DCSCN.py:222-325) as a list of graph layers and a
+// list of kernel launches over a small set of workspace tensors:
+//
+//   CONCAT  [n, H, W, sum(pad4(filters_i))]  every feature layer stores straight into its channel
+//                                            slice, so tf.concat (DCSCN.py:259) costs nothing
+//   T1      B1 output;  T2 = Concat2 = [B2 | A1] (DCSCN.py:281), or the "C" layer's output
+//   UPk     depth_to_space outputs (the shuffle happens in the producing conv's store)
+//   Rk      extra reconstruction layers;  DW  scratch of the depthwise half of separable convs
+//
+// All slices start on a 4-channel boundary and are padded to 4 channels; the consumer's repacked
+// filter has zero rows for padding channels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dcscn.h"
+#include "kernels.h"
+
+using namespace dcscn;
+
+namespace {
+
+thread_local std::string g_global_error;
+
+void set_global_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_global_error = buf;
+}
+
+inline int pad4(int c) { return (c + 3) & ~3; }
+inline int pad16(int c) { return (c + 15) & ~15; }
+
+enum { EXT_X = -1, EXT_X2 = -2, EXT_Y = -3 };
+enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2 };
+
+struct TensorSpec {
+    std::string name;
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool set = false;
+};
+
+struct WsBuf {
+    int stride = 0;       // floats per pixel
+    int res = 1;          // pixels per LR pixel along one axis
+    size_t offset = 0;    // byte offset inside the arena for the current layout
+};
+
+// one source block of a launch's filter matrix: conv channels [dst, dst + cout) come from `w`
+struct ColSeg {
+    int w = -1, b = -1, alpha = -1;   // tensor indices (-1 = absent)
+    int cout = 0;
+    int dst = 0;
+};
+
+struct Op {
+    OpKind kind = OP_CONV;
+    std::string name;
+    int ks = 3, cin = 0, cout = 0, res = 1;
+    int act = ACT_NONE;
+    float const_alpha = 0.0f;       // relu / leaky_relu slope when there is no alpha tensor
+    // input
+    int in_buf = EXT_X, in_off = 0, cin_phys = 0;
+    int in_stride_override = 0;     // > 0: pixel stride of the input differs from its buffer's
+    std::vector<int> chan_map;      // logical input channel -> physical channel relative to in_off
+    // filter sources
+    std::vector<ColSeg> segs;
+    int dw_w = -1;                  // depthwise filter tensor (OP_DW)
+    // output
+    int out_buf[2] = {EXT_Y, EXT_Y}, out_off[2] = {0, 0}, out_width[2] = {0, 0};
+    int split = 1 << 30;
+    int ps = 1, ps_c = 0;
+    bool residual = false;
+    bool vec4 = true;
+    // conv_igemm variant
+    ConvShape shape{3, 2, 1, 4};
+    int n_tiles = 1, n_chunks = 0, ctot = 0;
+    // accounting
+    int64_t macs = 0, bytes = 0;
+    // device copies
+    float* d_w = nullptr;
+    float* d_bias = nullptr;
+    float* d_alpha = nullptr;
+    int32_t* d_map = nullptr;
+};
+
+}  // namespace
+
+struct dcscn_ctx {
+    dcscn_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    bool finalized = false;
+
+    std::vector<int> sched;
+    std::vector<TensorSpec> tensors;
+    std::map<std::string, int> tensor_index;
+    std::vector<dcscn_layer_info> layers;
+    std::vector<WsBuf> bufs;
+    std::vector<Op> ops;
+
+    // workspace
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    int lay_n = 0, lay_h = 0, lay_w = 0;     // shape the current carve was made for
+    // host-path staging
+    float* io_x = nullptr; float* io_x2 = nullptr; float* io_y = nullptr;
+    size_t io_x_cap = 0, io_y_cap = 0;
+    std::vector<void*> device_allocs;
+
+    int64_t sub_batch_pixels = 128 * 48 * 48;
+    bool profile = false;
+    std::vector<hipEvent_t> ev;              // 2 per op per sub-batch slot
+    int ev_batches = 0;
+    std::vector<double> prof_ms;
+};
+
+namespace {
+
+int fail(dcscn_ctx* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->error = buf;
+    g_global_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, DCSCN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+#pragma clang fp contract(off)
+void filter_schedule(int layers, int filters, int min_filters, double gamma, std::vector<int>& out) {
+    // DCSCN.py:232,240-244 -- evaluated in double exactly as CPython does
+    out.clear();
+    int n = filters;
+    for (int i = 0; i < layers; ++i) {
+        if (min_filters != 0 && i > 0) {
+            const double x1 = (double)i / (double)(layers - 1);
+            const double y1 = std::pow(x1, 1.0 / gamma);
+            const double v = (double)(filters - min_filters) * (1.0 - y1) + (double)min_filters;
+            n = (int)v;
+        }
+        out.push_back(n);
+    }
+}
+
+int add_tensor(dcscn_ctx* h, const std::string& name, std::vector<int64_t> shape) {
+    TensorSpec t;
+    t.name = name;
+    t.shape = std::move(shape);
+    h->tensors.push_back(std::move(t));
+    h->tensor_index[name] = (int)h->tensors.size() - 1;
+    return (int)h->tensors.size() - 1;
+}
+
+int new_buf(dcscn_ctx* h, int stride, int res) {
+    WsBuf b;
+    b.stride = stride;
+    b.res = res;
+    h->bufs.push_back(b);
+    return (int)h->bufs.size() - 1;
+}
+
+int kernel_act(int activator, float* const_alpha) {
+    *const_alpha = 0.0f;
+    switch (activator) {
+        case DCSCN_ACT_NONE: return ACT_NONE;
+        case DCSCN_ACT_PRELU: return ACT_ALPHA;
+        case DCSCN_ACT_RELU: return ACT_ALPHA;
+        case DCSCN_ACT_LEAKY_RELU: *const_alpha = 0.1f; return ACT_ALPHA;   // tf.maximum(x, 0.1 x)
+        case DCSCN_ACT_SIGMOID: return ACT_SIGMOID;
+        case DCSCN_ACT_TANH: return ACT_TANH;
+        case DCSCN_ACT_SELU: return ACT_SELU;
+        default: return -1;
+    }
+}
+
+struct Src {            // where a layer reads its input
+    int buf = EXT_X;
+    int off = 0;
+    int cin = 0;        // logical channels
+    int cin_phys = 0;   // physical channels spanned (multiple of 4 unless external)
+    std::vector<int> map;
+    int res = 1;
+};
+
+Src identity_src(int buf, int off, int cin, int res) {
+    Src s;
+    s.buf = buf;
+    s.off = off;
+    s.cin = cin;
+    s.cin_phys = pad4(cin);
+    s.map.resize(cin);
+    for (int i = 0; i < cin; ++i) s.map[i] = i;
+    s.res = res;
+    return s;
+}
+
+struct Dst {
+    int buf = EXT_Y, off = 0, width = 0;
+    int ps = 1, ps_c = 0;
+    bool residual = false;
+};
+
+// Adds one graph conv layer (tf_graph.py build_conv / build_depthwise_separable_conv) and the
+// launch(es) that execute it. `short_name` is the layer name used for the prelu variable.
+void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_name, const Src& src, int ks,
+              int cout, bool bias, int activator, bool ds, const Dst& dst, int* dw_buf) {
+    const int cin = src.cin;
+    dcscn_layer_info li{};
+    snprintf(li.name, sizeof li.name, "%s", var.c_str());
+    li.kernel_size = ks;
+    li.in_channels = cin;
+    li.out_channels = cout;
+    li.depthwise_separable = ds;
+    li.has_bias = bias;
+    li.activator = activator;
+    li.resolution = src.res;
+    const int64_t r2 = (int64_t)src.res * src.res;
+    li.macs_per_lr_pixel = r2 * (ds ? (int64_t)ks * ks * cin + (int64_t)cin * cout : (int64_t)ks * ks * cin * cout);
+    h->layers.push_back(li);
+
+    ColSeg seg;
+    seg.cout = cout;
+    seg.dst = 0;
+    int t_dw = -1;
+    if (ds) {
+        t_dw = add_tensor(h, var + "/depthwise_W", {ks, ks, cin, 1});
+        seg.w = add_tensor(h, var + "/pointwise_W", {1, 1, cin, cout});
+    } else {
+        seg.w = add_tensor(h, var + "/conv_W", {ks, ks, cin, cout});
+    }
+    if (bias) seg.b = add_tensor(h, var + "/conv_B", {cout});
+    if (activator == DCSCN_ACT_PRELU) seg.alpha = add_tensor(h, var + "/prelu/" + short_name + "_prelu", {cout});
+
+    Op op;
+    op.name = var;
+    op.res = src.res;
+    op.cout = cout;
+    op.act = kernel_act(activator, &op.const_alpha);
+    op.segs.push_back(seg);
+    op.out_buf[0] = dst.buf;
+    op.out_off[0] = dst.off;
+    op.out_width[0] = dst.width;
+    op.ps = dst.ps;
+    op.ps_c = dst.ps_c;
+    op.residual = dst.residual;
+    const int out_stride = dst.buf >= 0 ? h->bufs[dst.buf].stride : 1;
+    op.vec4 = out_stride % 4 == 0 && dst.off % 4 == 0 && dst.width % 4 == 0 && (dst.ps == 1 || dst.ps_c % 4 == 0) &&
+              !dst.residual;
+    const int64_t out_bytes = 4 * r2 * dst.width;
+
+    if (ds) {
+        // depthwise half -> DW scratch (logical channel order, zero padded to 4)
+        if (*dw_buf < 0) *dw_buf = new_buf(h, 4, 1);
+        Op dw;
+        dw.kind = OP_DW;
+        dw.name = var + "/depthwise";
+        dw.ks = ks;
+        dw.cin = cin;
+        dw.cout = cin;
+        dw.res = src.res;
+        dw.in_buf = src.buf;
+        dw.in_off = src.off;
+        dw.cin_phys = pad4(cin);
+        dw.chan_map = src.map;
+        dw.dw_w = t_dw;
+        dw.out_buf[0] = *dw_buf;
+        dw.macs = r2 * (int64_t)ks * ks * cin;
+        dw.bytes = 4 * r2 * (cin + pad4(cin));
+        h->ops.push_back(dw);
+
+        op.kind = OP_CONV;
+        op.ks = 1;
+        op.cin = cin;
+        op.in_buf = *dw_buf;
+        op.in_off = 0;
+        op.in_stride_override = pad4(cin);
+        op.cin_phys = pad4(cin);
+        op.chan_map.resize(cin);
+        for (int i = 0; i < cin; ++i) op.chan_map[i] = i;
+        op.macs = r2 * (int64_t)cin * cout;
+        op.bytes = 4 * r2 * pad4(cin) + out_bytes;
+    } else if (src.buf == EXT_X) {
+        op.kind = OP_CIN1;
+        op.ks = ks;
+        op.cin = 1;
+        op.in_buf = EXT_X;
+        op.macs = r2 * (int64_t)ks * ks * cout;
+        op.bytes = 4 * r2 + out_bytes;
+    } else {
+        op.kind = OP_CONV;
+        op.ks = ks;
+        op.cin = cin;
+        op.in_buf = src.buf;
+        op.in_off = src.off;
+        op.cin_phys = src.cin_phys;
+        op.chan_map = src.map;
+        op.macs = li.macs_per_lr_pixel;
+        op.bytes = 4 * r2 * src.cin_phys + out_bytes;
+    }
+    h->ops.push_back(op);
+}
+
+int build_graph(dcscn_ctx* h) {
+    const dcscn_config& c = h->cfg;
+    const bool ds = c.depthwise_separable != 0;
+    const int k = c.cnn_size;
+    int dw_buf = -1;
+
+    filter_schedule(c.layers, c.filters, c.min_filters, c.filters_decay_gamma, h->sched);
+    std::vector<int> slice_off(c.layers);
+    int concat_stride = 0, total = 0;
+    for (int i = 0; i < c.layers; ++i) {
+        if (h->sched[i] <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "feature layer %d has %d filters", i + 1, h->sched[i]);
+        slice_off[i] = concat_stride;
+        concat_stride += pad4(h->sched[i]);
+        total += h->sched[i];
+    }
+    const int concat = new_buf(h, concat_stride, 1);
+
+    // feature extraction, DCSCN.py:240-256
+    Src src;
+    src.buf = EXT_X;
+    src.cin = c.channels;
+    src.cin_phys = c.channels;
+    src.map = {0};
+    src.res = 1;
+    for (int i = 0; i < c.layers; ++i) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "CNN%d", i + 1);
+        Dst d;
+        d.buf = concat;
+        d.off = slice_off[i];
+        d.width = pad4(h->sched[i]);
+        add_conv(h, nm, nm, src, k, h->sched[i], true, c.activator, ds, d, &dw_buf);
+        src = identity_src(concat, slice_off[i], h->sched[i], 1);
+    }
+    Src cat;   // H_concat as an input
+    cat.buf = concat;
+    cat.off = 0;
+    cat.cin = total;
+    cat.cin_phys = concat_stride;
+    cat.res = 1;
+    for (int i = 0; i < c.layers; ++i)
+        for (int j = 0; j < h->sched[i]; ++j) cat.map.push_back(slice_off[i] + j);
+
+    // reconstruction, DCSCN.py:262-291
+    if (c.use_nin) {
+        const int na = c.nin_filters, nb = c.nin_filters2;
+        if (na <= 0 || nb <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "nin_filters / nin_filters2 must be positive");
+        const int t1 = new_buf(h, pad4(nb), 1);
+        const int t2 = new_buf(h, pad4(nb) + pad4(na), 1);
+        Dst da, db;
+        da.buf = t2; da.off = pad4(nb); da.width = pad4(na);
+        db.buf = t1; db.off = 0; db.width = pad4(nb);
+        add_conv(h, "A1", "A1", cat, 1, na, true, c.activator, ds, da, &dw_buf);
+        add_conv(h, "B1", "B1", cat, 1, nb, true, c.activator, ds, db, &dw_buf);
+        if (!ds) {
+            // A1 and B1 read the same 1301-wide concat: run them as ONE GEMM with conv channels
+            // [B1 | pad to 16 | A1] and two destinations (halves the concat traffic).
+            Op b1 = h->ops.back();
+            h->ops.pop_back();
+            Op a1 = h->ops.back();
+            h->ops.pop_back();
+            Op f = a1;
+            f.name = "B1+A1";
+            f.cout = na + nb;
+            f.segs.clear();
+            ColSeg sb = b1.segs[0];
+            sb.dst = 0;
+            ColSeg sa = a1.segs[0];
+            sa.dst = pad16(nb);
+            f.segs.push_back(sb);
+            f.segs.push_back(sa);
+            f.split = pad16(nb);
+            f.out_buf[0] = t1; f.out_off[0] = 0; f.out_width[0] = pad4(nb);
+            f.out_buf[1] = t2; f.out_off[1] = pad4(nb); f.out_width[1] = pad4(na);
+            f.macs = a1.macs + b1.macs;
+            f.bytes = 4 * (int64_t)concat_stride + 4 * (pad4(na) + pad4(nb));
+            h->ops.push_back(f);
+        }
+        Dst d2;
+        d2.buf = t2; d2.off = 0; d2.width = pad4(nb);
+        add_conv(h, "B2", "B2", identity_src(t1, 0, nb, 1), 3, nb, true, c.activator, ds, d2, &dw_buf);
+        src = Src();
+        src.buf = t2;
+        src.off = 0;
+        src.cin = na + nb;
+        src.cin_phys = pad4(nb) + pad4(na);
+        src.res = 1;
+        for (int j = 0; j < nb; ++j) src.map.push_back(j);                 // Concat2 = [B2, A1]
+        for (int j = 0; j < na; ++j) src.map.push_back(pad4(nb) + j);
+    } else if (c.legacy_no_c) {
+        src = cat;
+    } else {
+        const int t2 = new_buf(h, pad4(c.filters), 1);
+        Dst d;
+        d.buf = t2; d.off = 0; d.width = pad4(c.filters);
+        add_conv(h, "C", "C", cat, 1, c.filters, true, c.activator, ds, d, &dw_buf);
+        src = identity_src(t2, 0, c.filters, 1);
+    }
+
+    // upsampling, DCSCN.py:293-311 + tf_graph.py:238-249
+    const int ps_out = c.pixel_shuffler_filters != 0 ? c.pixel_shuffler_filters : src.cin;
+    struct Stage { const char* name; int s; int cout; };
+    std::vector<Stage> stages;
+    if (c.scale == 4) {
+        stages.push_back({"Up-PS", 2, src.cin});
+        stages.push_back({"Up-PS2", 2, ps_out});
+    } else {
+        stages.push_back({"Up-PS", c.scale, ps_out});
+    }
+    for (const Stage& st : stages) {
+        const int ub = new_buf(h, pad4(st.cout), src.res * st.s);
+        Dst d;
+        d.buf = ub; d.off = 0; d.width = st.s * st.s * st.cout;
+        d.ps = st.s; d.ps_c = st.cout;
+        const std::string var = std::string(st.name) + "/" + st.name + "_CNN";
+        add_conv(h, var, std::string(st.name) + "_CNN", src, k, st.s * st.s * st.cout, true, DCSCN_ACT_NONE, ds, d, &dw_buf);
+        src = identity_src(ub, 0, st.cout, src.res * st.s);
+    }
+
+    // reconstruction convs at HR, DCSCN.py:313-323
+    const int rl = std::max(c.reconstruct_layers, 1);
+    for (int i = 0; i < rl - 1; ++i) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "R-CNN%d", i + 1);
+        const int rb = new_buf(h, pad4(c.reconstruct_filters), src.res);
+        Dst d;
+        d.buf = rb; d.off = 0; d.width = pad4(c.reconstruct_filters);
+        add_conv(h, nm, nm, src, k, c.reconstruct_filters, true, c.activator, false, d, &dw_buf);
+        src = identity_src(rb, 0, c.reconstruct_filters, src.res);
+    }
+    {
+        char nm[32];
+        snprintf(nm, sizeof nm, "R-CNN%d", rl);
+        Dst d;
+        d.buf = EXT_Y; d.off = 0; d.width = 1;
+        d.residual = true;                                                  // y_ = R-CNN + x2, DCSCN.py:325
+        add_conv(h, nm, nm, src, k, 1, false, DCSCN_ACT_NONE, ds, d, &dw_buf);
+    }
+    if (src.res != c.scale) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: output resolution %d != scale %d", src.res, c.scale);
+
+    // size the depthwise scratch: widest separable input at its resolution (per pixel: stride floats)
+    if (dw_buf >= 0) {
+        // one stride per resolution would waste nothing, but a single shared tensor is simpler: give it
+        // the largest per-LR-pixel footprint by choosing res = 1 and stride = max(res^2 * pad4(cin)).
+        int best = 4;
+        for (const Op& op : h->ops)
+            if (op.kind == OP_DW) best = std::max(best, op.res * op.res * pad4(op.cin));
+        h->bufs[dw_buf].stride = best;
+        h->bufs[dw_buf].res = 1;
+    }
+    return DCSCN_OK;
+}
+
+// ---- weight repack -----------------------------------------------------------------------------
+
+int upload(dcscn_ctx* h, const void* host, size_t bytes, void** dev) {
+    HIP_TRY(h, hipMalloc(dev, bytes));
+    h->device_allocs.push_back(*dev);
+    HIP_TRY(h, hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+    return DCSCN_OK;
+}
+
+int finalize_op(dcscn_ctx* h, Op& op) {
+    if (op.kind == OP_DW) {
+        const TensorSpec& w = h->tensors[op.dw_w];          // [k, k, cin, 1] -> [taps][cin]
+        int rc = upload(h, w.data.data(), w.data.size() * sizeof(float), (void**)&op.d_w);
+        if (rc) return rc;
+        std::vector<int32_t> map(op.chan_map.begin(), op.chan_map.end());
+        return upload(h, map.data(), map.size() * sizeof(int32_t), (void**)&op.d_map);
+    }
+
+    const int taps = op.ks * op.ks;
+    if (op.kind == OP_CIN1) {
+        const ColSeg& s = op.segs[0];
+        const int cs = op.out_width[0];
+        std::vector<float> w((size_t)taps * cs, 0.0f), b(cs, 0.0f), al(cs, op.const_alpha);
+        const TensorSpec& tw = h->tensors[s.w];             // [k, k, 1, cout]
+        for (int t = 0; t < taps; ++t)
+            for (int c = 0; c < s.cout; ++c) w[(size_t)t * cs + c] = tw.data[(size_t)t * s.cout + c];
+        if (s.b >= 0) std::copy(h->tensors[s.b].data.begin(), h->tensors[s.b].data.end(), b.begin());
+        if (s.alpha >= 0) std::copy(h->tensors[s.alpha].data.begin(), h->tensors[s.alpha].data.end(), al.begin());
+        for (int c = s.cout; c < cs; ++c) al[c] = 0.0f;
+        int rc = upload(h, w.data(), w.size() * sizeof(float), (void**)&op.d_w);
+        if (!rc) rc = upload(h, b.data(), b.size() * sizeof(float), (void**)&op.d_bias);
+        if (!rc) rc = upload(h, al.data(), al.size() * sizeof(float), (void**)&op.d_alpha);
+        return rc;
+    }
+
+    // OP_CONV: dense [tap][k_phys][conv channel] -> [n_tile][chunk][tap][kk][NS]
+    int ctot = 0;
+    for (const ColSeg& s : op.segs) ctot = std::max(ctot, s.dst + s.cout);
+    const int tiles16 = (ctot + 15) / 16;
+    op.n_tiles = (tiles16 + 12) / 13;
+    const int nt = (tiles16 + op.n_tiles - 1) / op.n_tiles;
+    op.shape = conv_pick_shape(op.ks, nt);
+    op.ctot = op.n_tiles * nt * 16;
+    const int kc = op.shape.kc;
+    op.n_chunks = (op.cin_phys + kc - 1) / kc;
+    const int ns = conv_ns(nt);
+    const size_t chunk_floats = (size_t)taps * kc * ns;
+    std::vector<float> pack((size_t)op.n_tiles * op.n_chunks * chunk_floats, 0.0f);
+    std::vector<float> bias(op.ctot, 0.0f), alpha(op.ctot, 0.0f);
+    for (const ColSeg& s : op.segs) {
+        const TensorSpec& tw = h->tensors[s.w];             // [ks, ks, cin, cout] (or [1,1,cin,cout])
+        const int cin = (int)op.chan_map.size();
+        for (int t = 0; t < taps; ++t)
+            for (int ci = 0; ci < cin; ++ci) {
+                const int kp = op.chan_map[ci];
+                const int chunk = kp / kc, kk = kp % kc;
+                const float* wrow = &tw.data[((size_t)t * cin + ci) * s.cout];
+                for (int co = 0; co < s.cout; ++co) {
+                    const int cc = s.dst + co;
+                    const int tile = cc / (nt * 16), j = cc % (nt * 16);
+                    pack[((size_t)tile * op.n_chunks + chunk) * chunk_floats + ((size_t)t * kc + kk) * ns + j] = wrow[co];
+                }
+            }
+        for (int co = 0; co < s.cout; ++co) {
+            if (s.b >= 0) bias[s.dst + co] = h->tensors[s.b].data[co];
+            alpha[s.dst + co] = s.alpha >= 0 ? h->tensors[s.alpha].data[co] : op.const_alpha;
+        }
+    }
+    int rc = upload(h, pack.data(), pack.size() * sizeof(float), (void**)&op.d_w);
+    if (!rc) rc = upload(h, bias.data(), bias.size() * sizeof(float), (void**)&op.d_bias);
+    if (!rc) rc = upload(h, alpha.data(), alpha.size() * sizeof(float), (void**)&op.d_alpha);
+    return rc;
+}
+
+// ---- workspace ---------------------------------------------------------------------------------
+
+int ensure_workspace(dcscn_ctx* h, int nb, int H, int W) {
+    if (h->arena && nb <= h->lay_n && H == h->lay_h && W == h->lay_w) return DCSCN_OK;
+    size_t total = 0;
+    for (WsBuf& b : h->bufs) {
+        b.offset = total;
+        const size_t bytes = (size_t)nb * H * b.res * W * b.res * b.stride * sizeof(float);
+        total += (bytes + 255) & ~(size_t)255;
+    }
+    total = std::max<size_t>(total, 256);
+    if (total > h->arena_bytes) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->arena) HIP_TRY(h, hipFree(h->arena));
+        h->arena = nullptr;
+        h->arena_bytes = 0;
+        hipError_t e = hipMalloc(&h->arena, total);
+        if (e != hipSuccess) return fail(h, DCSCN_ERR_NOMEM, "workspace of %zu bytes: %s", total, hipGetErrorString(e));
+        h->arena_bytes = total;
+    }
+    // padding channels that no kernel writes (depth_to_space outputs with C % 4 != 0) must hold
+    // finite values: clear the whole arena whenever the carve changes
+    HIP_TRY(h, hipMemsetAsync(h->arena, 0, h->arena_bytes, h->stream));
+    h->lay_n = nb;
+    h->lay_h = H;
+    h->lay_w = W;
+    return DCSCN_OK;
+}
+
+inline float* buf_ptr(dcscn_ctx* h, int id) { return reinterpret_cast<float*>(static_cast<char*>(h->arena) + h->bufs[id].offset); }
+
+int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, const float* x2, float* y,
+              hipStream_t stream) {
+    const int Hr = H * op.res, Wr = W * op.res;
+    if (op.kind == OP_DW) {
+        DwArgs a{};
+        a.in = op.in_buf == EXT_X ? x : buf_ptr(h, op.in_buf);
+        a.in_stride = op.in_buf == EXT_X ? 1 : h->bufs[op.in_buf].stride;
+        a.in_off = op.in_off;
+        a.chan_map = op.d_map;
+        a.w = op.d_w;
+        a.ks = op.ks;
+        a.cin = op.cin;
+        a.cout_phys = pad4(op.cin);
+        a.N = nb; a.H = Hr; a.W = Wr;
+        a.out = buf_ptr(h, op.out_buf[0]);
+        a.out_stride = pad4(op.cin);
+        HIP_TRY(h, depthwise_launch(a, stream));
+        return DCSCN_OK;
+    }
+    if (op.kind == OP_CIN1) {
+        Cin1Args a{};
+        a.x = x;
+        a.w = op.d_w; a.bias = op.d_bias; a.alpha = op.d_alpha;
+        a.act = op.act;
+        a.ks = op.ks;
+        a.N = nb; a.H = Hr; a.W = Wr;
+        a.cs = op.out_width[0];
+        a.out.ptr = buf_ptr(h, op.out_buf[0]);
+        a.out.stride = h->bufs[op.out_buf[0]].stride;
+        a.out.off = op.out_off[0];
+        a.out.width = op.out_width[0];
+        HIP_TRY(h, cin1_launch(a, stream));
+        return DCSCN_OK;
+    }
+    ConvArgs a{};
+    a.in = buf_ptr(h, op.in_buf);
+    // the depthwise scratch is re-strided per use (pad4(cin) of the separable conv that filled it)
+    a.in_stride = op.in_stride_override > 0 ? op.in_stride_override : h->bufs[op.in_buf].stride;
+    a.in_off = op.in_off;
+    a.cin_phys = op.cin_phys;
+    a.n_chunks = op.n_chunks;
+    a.wpack = op.d_w; a.bias = op.d_bias; a.alpha = op.d_alpha;
+    a.act = op.act;
+    a.N = nb; a.H = Hr; a.W = Wr;
+    a.tiles_x = (Wr + 15) / 16;
+    a.tiles_y = (Hr + 4 * op.shape.mt - 1) / (4 * op.shape.mt);
+    for (int i = 0; i < 2; ++i) {
+        OutDesc& o = i == 0 ? a.out0 : a.out1;
+        const int id = op.out_buf[i];
+        o.ptr = id == EXT_Y ? y : buf_ptr(h, id);
+        o.stride = id == EXT_Y ? 1 : h->bufs[id].stride;
+        o.off = op.out_off[i];
+        o.width = op.out_width[i];
+    }
+    a.split = op.split;
+    a.ps = op.ps;
+    a.ps_c = op.ps == 1 ? 1 : op.ps_c;
+    a.vec4 = op.vec4 ? 1 : 0;
+    a.res = op.residual ? x2 : nullptr;
+    a.res_stride = 1;
+    HIP_TRY(h, conv_launch(op.shape, a, op.n_tiles, stream));
+    return DCSCN_OK;
+}
+
+int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, int H, int W, hipStream_t stream) {
+    if (!h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_forward before dcscn_finalize");
+    if (n < 0 || H <= 0 || W <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape n=%d h=%d w=%d", n, H, W);
+    if (n == 0) return DCSCN_OK;
+    if (!x || !x2 || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t per_image = (int64_t)H * W;
+    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(n, h->sub_batch_pixels / per_image));
+    int rc = ensure_workspace(h, nb, H, W);
+    if (rc) return rc;
+    if (stream != h->stream) {
+        // order the (possible) arena clear on our stream before work on the caller's stream
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    const int s = h->cfg.scale;
+    const int batches = (n + nb - 1) / nb;
+    const int nops = (int)h->ops.size();
+    if (h->profile) {
+        const size_t need = (size_t)batches * nops * 2;
+        while (h->ev.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(h, hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        h->ev_batches = batches;
+    } else {
+        h->ev_batches = 0;
+    }
+    for (int b = 0; b < batches; ++b) {
+        const int b0 = b * nb;
+        const int cnt = std::min(nb, n - b0);
+        const float* xb = x + (size_t)b0 * H * W;
+        const float* x2b = x2 + (size_t)b0 * H * s * W * s;
+        float* yb = y + (size_t)b0 * H * s * W * s;
+        for (int i = 0; i < nops; ++i) {
+            if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[((size_t)b * nops + i) * 2], stream));
+            rc = launch_op(h, h->ops[i], cnt, H, W, xb, x2b, yb, stream);
+            if (rc) return rc;
+            if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[((size_t)b * nops + i) * 2 + 1], stream));
+        }
+    }
+    return DCSCN_OK;
+}
+
+// flip / rotate index maps of helper/utilty.py:595-617: transformed[r][c] = image[src_r][src_c]
+inline void flip_src(int type, int h, int w, int r, int c, int* sr, int* sc) {
+    switch (type) {
+        case 0: *sr = r; *sc = c; break;
+        case 1: *sr = h - 1 - r; *sc = c; break;                // flipud
+        case 2: *sr = r; *sc = w - 1 - c; break;                // fliplr
+        case 3: *sr = h - 1 - r; *sc = w - 1 - c; break;        // flipud(fliplr)
+        case 4: *sr = c; *sc = w - 1 - r; break;                // rot90(+1): shape [w, h]
+        case 5: *sr = h - 1 - c; *sc = r; break;                // rot90(-1)
+        case 6: *sr = c; *sc = r; break;                        // flipud(rot90(+1)) = transpose
+        default: *sr = h - 1 - c; *sc = w - 1 - r; break;       // flipud(rot90(-1)) = anti-transpose
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int dcscn_abi_version(void) { return DCSCN_ABI_VERSION; }
+
+const char* dcscn_last_global_error(void) { return g_global_error.c_str(); }
+
+int dcscn_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_global_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return -DCSCN_ERR_HIP;
+    }
+    return n;
+}
+
+int dcscn_filter_schedule(int layers, int filters, int min_filters, double gamma, int32_t* out) {
+    if (!out || layers <= 0 || gamma <= 0.0) {
+        set_global_error("dcscn_filter_schedule: bad arguments");
+        return DCSCN_ERR_INVALID_ARG;
+    }
+    std::vector<int> s;
+    filter_schedule(layers, filters, std::min(filters, min_filters), gamma, s);
+    for (int i = 0; i < layers; ++i) out[i] = s[i];
+    return DCSCN_OK;
+}
+
+int dcscn_create(const dcscn_config* cfg, int device, dcscn_handle* out) {
+    if (!cfg || !out) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "dcscn_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(dcscn_config))
+        return fail(nullptr, DCSCN_ERR_INVALID_ARG, "dcscn_create: struct_size %d != %zu", cfg->struct_size, sizeof(dcscn_config));
+    dcscn_config c = *cfg;
+    c.min_filters = std::min(c.filters, c.min_filters);                     // DCSCN.py:36
+    c.reconstruct_layers = std::max(c.reconstruct_layers, 1);               // DCSCN.py:42
+    if (c.scale < 2 || c.scale > 4) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "scale %d (supported: 2, 3, 4)", c.scale);
+    if (c.layers < 1 || c.layers > 256 || c.filters < 1) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "bad layers/filters");
+    if (c.layers > 1 && !(c.filters_decay_gamma > 0.0)) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "filters_decay_gamma must be > 0");
+    if (c.cnn_size != 3 && c.cnn_size != 1) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "cnn_size %d (supported: 3, 1)", c.cnn_size);
+    if (c.channels != 1) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "channels %d (the reference itself only supports 1)", c.channels);
+    if (!c.pixel_shuffler) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "transposed-conv upsampler (pixel_shuffler=false) is not implemented");
+    if (c.batch_norm) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "batch_norm is not implemented");
+    float dummy;
+    if (kernel_act(c.activator, &dummy) < 0) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "Not implemented activator:%d", c.activator);
+    if (c.legacy_no_c && c.use_nin) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "legacy_no_c requires use_nin = 0");
+    if (c.reconstruct_layers > 1 && c.reconstruct_filters < 1) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "reconstruct_filters must be positive");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, DCSCN_ERR_HIP, "no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "device %d out of range [0, %d)", device, ndev);
+
+    dcscn_ctx* h = new (std::nothrow) dcscn_ctx();
+    if (!h) return fail(nullptr, DCSCN_ERR_NOMEM, "out of host memory");
+    h->cfg = c;
+    h->device = device;
+    int rc = DCSCN_OK;
+    do {
+        if ((e = hipSetDevice(device)) != hipSuccess) { rc = fail(h, DCSCN_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e)); break; }
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { rc = fail(h, DCSCN_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); break; }
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            rc = fail(h, DCSCN_ERR_HIP, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+            break;
+        }
+        if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(h, DCSCN_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
+        if ((e = conv_init_kernels()) != hipSuccess) { rc = fail(h, DCSCN_ERR_HIP, "kernel attribute setup: %s", hipGetErrorString(e)); break; }
+        rc = build_graph(h);
+    } while (0);
+    if (rc != DCSCN_OK) {
+        g_global_error = h->error;
+        dcscn_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return DCSCN_OK;
+}
+
+int dcscn_num_tensors(dcscn_handle h) { return h ? (int)h->tensors.size() : -DCSCN_ERR_INVALID_ARG; }
+
+int dcscn_tensor_info(dcscn_handle h, int index, char* name, int name_capacity, int64_t* shape, int* rank) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (index < 0 || index >= (int)h->tensors.size() || !name || name_capacity <= 0 || !shape || !rank)
+        return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_tensor_info: bad argument");
+    const TensorSpec& t = h->tensors[index];
+    snprintf(name, (size_t)name_capacity, "%s", t.name.c_str());
+    *rank = (int)t.shape.size();
+    for (int i = 0; i < 4; ++i) shape[i] = i < *rank ? t.shape[i] : 1;
+    return DCSCN_OK;
+}
+
+int dcscn_set_tensor(dcscn_handle h, const char* name, const float* data, const int64_t* shape, int rank) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!name || !data || !shape) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_set_tensor: null argument");
+    if (h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_set_tensor after dcscn_finalize");
+    auto it = h->tensor_index.find(name);
+    if (it == h->tensor_index.end()) return fail(h, DCSCN_ERR_SHAPE, "variable '%s' is not part of this graph", name);
+    TensorSpec& t = h->tensors[it->second];
+    bool same = rank == (int)t.shape.size();
+    for (int i = 0; same && i < rank; ++i) same = shape[i] == t.shape[i];
+    if (!same) {
+        std::string want, got;
+        for (int64_t d : t.shape) want += std::to_string(d) + ",";
+        for (int i = 0; i < rank && i < 8; ++i) got += std::to_string(shape[i]) + ",";
+        return fail(h, DCSCN_ERR_SHAPE, "variable '%s': shape [%s] does not match graph shape [%s]", name, got.c_str(), want.c_str());
+    }
+    size_t count = 1;
+    for (int64_t d : t.shape) count *= (size_t)d;
+    for (size_t i = 0; i < count; ++i)
+        if (!std::isfinite(data[i])) return fail(h, DCSCN_ERR_INVALID_ARG, "variable '%s' holds a non-finite value", name);
+    t.data.assign(data, data + count);
+    t.set = true;
+    return DCSCN_OK;
+}
+
+int dcscn_finalize(dcscn_handle h) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (h->finalized) return DCSCN_OK;
+    for (const TensorSpec& t : h->tensors)
+        if (!t.set) return fail(h, DCSCN_ERR_MISSING_TENSOR, "variable '%s' was never set", t.name.c_str());
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (Op& op : h->ops) {
+        int rc = finalize_op(h, op);
+        if (rc) return rc;
+    }
+    h->prof_ms.assign(h->ops.size(), 0.0);
+    h->finalized = true;
+    return DCSCN_OK;
+}
+
+int dcscn_num_layers(dcscn_handle h) { return h ? (int)h->layers.size() : -DCSCN_ERR_INVALID_ARG; }
+
+int dcscn_layer_info_get(dcscn_handle h, int index, dcscn_layer_info* out) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!out || index < 0 || index >= (int)h->layers.size()) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_layer_info_get: bad argument");
+    *out = h->layers[index];
+    return DCSCN_OK;
+}
+
+int dcscn_num_ops(dcscn_handle h) { return h ? (int)h->ops.size() : -DCSCN_ERR_INVALID_ARG; }
+
+int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!out || index < 0 || index >= (int)h->ops.size()) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_op_info_get: bad argument");
+    const Op& op = h->ops[index];
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
+    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? "conv_igemm" : op.kind == OP_CIN1 ? "conv_cin1" : "depthwise");
+    out->kernel_size = op.ks;
+    out->in_channels = op.cin;
+    out->out_channels = op.cout;
+    out->resolution = op.res;
+    if (op.kind == OP_CONV && h->finalized) {
+        out->mt = op.shape.mt; out->nt = op.shape.nt; out->kc = op.shape.kc; out->n_tiles = op.n_tiles;
+    }
+    out->macs_per_lr_pixel = op.macs;
+    out->bytes_per_lr_pixel = op.bytes;
+    return DCSCN_OK;
+}
+
+int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!key) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_set_option: null key");
+    if (!strcmp(key, "sub_batch_pixels")) {
+        if (value < 1) return fail(h, DCSCN_ERR_INVALID_ARG, "sub_batch_pixels must be >= 1");
+        h->sub_batch_pixels = value;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "profile")) {
+        h->profile = value != 0;
+        return DCSCN_OK;
+    }
+    return fail(h, DCSCN_ERR_INVALID_ARG, "unknown option '%s'", key);
+}
+
+int dcscn_forward_device(dcscn_handle h, const float* x, const float* x2, float* y, int n, int height, int width, void* stream) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    return run_forward(h, x, x2, y, n, height, width, stream ? (hipStream_t)stream : h->stream);
+}
+
+static int ensure_io(dcscn_ctx* h, size_t lr_floats, size_t hr_floats) {
+    if (lr_floats > h->io_x_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->io_x) HIP_TRY(h, hipFree(h->io_x));
+        h->io_x = nullptr; h->io_x_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->io_x, lr_floats * sizeof(float)));
+        h->io_x_cap = lr_floats;
+    }
+    if (hr_floats > h->io_y_cap) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->io_x2) HIP_TRY(h, hipFree(h->io_x2));
+        if (h->io_y) HIP_TRY(h, hipFree(h->io_y));
+        h->io_x2 = h->io_y = nullptr; h->io_y_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->io_x2, hr_floats * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->io_y, hr_floats * sizeof(float)));
+        h->io_y_cap = hr_floats;
+    }
+    return DCSCN_OK;
+}
+
+int dcscn_forward(dcscn_handle h, const float* x, const float* x2, float* y, int n, int height, int width) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_forward before dcscn_finalize");
+    if (n < 0 || height <= 0 || width <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape n=%d h=%d w=%d", n, height, width);
+    if (n == 0) return DCSCN_OK;
+    if (!x || !x2 || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int s = h->cfg.scale;
+    const size_t lr = (size_t)n * height * width, hr = lr * s * s;
+    int rc = ensure_io(h, lr, hr);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->io_x, x, lr * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->io_x2, x2, hr * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    rc = run_forward(h, h->io_x, h->io_x2, h->io_y, n, height, width, h->stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(y, h->io_y, hr * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DCSCN_OK;
+}
+
+int dcscn_forward_ensemble(dcscn_handle h, const float* x, const float* x2, double* y, int height, int width, int n_ensemble) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!x || !x2 || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
+    if (n_ensemble < 1 || n_ensemble > 8) return fail(h, DCSCN_ERR_INVALID_ARG, "n_ensemble %d outside [1, 8]", n_ensemble);
+    if (height <= 0 || width <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape h=%d w=%d", height, width);
+    const int s = h->cfg.scale;
+    const size_t lr = (size_t)height * width, hr = lr * s * s;
+    const int na = std::min(n_ensemble, 4), nb = n_ensemble - na;   // types 0-3 keep [h, w]; 4-7 are [w, h]
+    std::vector<float> xin((size_t)n_ensemble * lr), x2in((size_t)n_ensemble * hr), yout((size_t)n_ensemble * hr);
+    for (int t = 0; t < n_ensemble; ++t) {
+        const bool rot = t >= 4;
+        const int th = rot ? width : height, tw = rot ? height : width;
+        float* xd = &xin[(size_t)t * lr];
+        float* x2d = &x2in[(size_t)t * hr];
+        for (int r = 0; r < th; ++r)
+            for (int c = 0; c < tw; ++c) {
+                int sr, sc;
+                flip_src(t, height, width, r, c, &sr, &sc);
+                xd[(size_t)r * tw + c] = x[(size_t)sr * width + sc];
+            }
+        const int Th = th * s, Tw = tw * s, Hh = height * s, Ww = width * s;
+        for (int r = 0; r < Th; ++r)
+            for (int c = 0; c < Tw; ++c) {
+                int sr, sc;
+                flip_src(t, Hh, Ww, r, c, &sr, &sc);
+                x2d[(size_t)r * Tw + c] = x2[(size_t)sr * Ww + sc];
+            }
+    }
+    int rc = dcscn_forward(h, xin.data(), x2in.data(), yout.data(), na, height, width);
+    if (rc) return rc;
+    if (nb > 0) {
+        rc = dcscn_forward(h, &xin[4 * lr], &x2in[4 * hr], &yout[4 * hr], nb, width, height);
+        if (rc) return rc;
+    }
+    // output = zeros; output += restored_i (i ascending); output /= n   (DCSCN.py:560-573), float64
+    for (size_t i = 0; i < hr; ++i) y[i] = 0.0;
+    const int Hh = height * s, Ww = width * s;
+    for (int t = 0; t < n_ensemble; ++t) {
+        const bool rot = t >= 4;
+        const int Th = (rot ? width : height) * s, Tw = (rot ? height : width) * s;
+        const float* yt = &yout[(size_t)t * hr];
+        for (int r = 0; r < Th; ++r)
+            for (int c = 0; c < Tw; ++c) {
+                int sr, sc;
+                flip_src(t, Hh, Ww, r, c, &sr, &sc);
+                y[(size_t)sr * Ww + sc] += (double)yt[(size_t)r * Tw + c];
+            }
+    }
+    if (n_ensemble > 1)
+        for (size_t i = 0; i < hr; ++i) y[i] /= (double)n_ensemble;
+    return DCSCN_OK;
+}
+
+int dcscn_get_profile(dcscn_handle h, double* ms, int capacity) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!ms || capacity < 0) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_get_profile: bad argument");
+    const int nops = (int)h->ops.size();
+    std::vector<double> acc(nops, 0.0);
+    if (h->ev_batches > 0) {
+        HIP_TRY(h, hipDeviceSynchronize());
+        for (int b = 0; b < h->ev_batches; ++b)
+            for (int i = 0; i < nops; ++i) {
+                float t = 0.0f;
+                HIP_TRY(h, hipEventElapsedTime(&t, h->ev[((size_t)b * nops + i) * 2], h->ev[((size_t)b * nops + i) * 2 + 1]));
+                acc[i] += t;
+            }
+    }
+    for (int i = 0; i < std::min(capacity, nops); ++i) ms[i] = acc[i];
+    return DCSCN_OK;
+}
+
+int64_t dcscn_workspace_bytes(dcscn_handle h) { return h ? (int64_t)h->arena_bytes : -1; }
+
+const char* dcscn_last_error(dcscn_handle h) { return h ? h->error.c_str() : g_global_error.c_str(); }
+
+int dcscn_destroy(dcscn_handle h) {
+    if (!h) return DCSCN_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (void* p : h->device_allocs) (void)hipFree(p);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->io_x) (void)hipFree(h->io_x);
+    if (h->io_x2) (void)hipFree(h->io_x2);
+    if (h->io_y) (void)hipFree(h->io_y);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return DCSCN_OK;
+}
+
+}  // extern "C"

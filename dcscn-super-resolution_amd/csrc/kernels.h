@@ -1,0 +1,86 @@
+// Internal interface between the plan/ABI layer (api.hip) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dcscn {
+
+// Activation codes as the kernels see them (build_activator, helper/tf_graph.py:77-102).
+// prelu / relu / leaky_relu all become ACT_ALPHA with a per-channel negative slope.
+enum { ACT_NONE = 0, ACT_ALPHA = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_SELU = 4 };
+
+struct OutDesc {
+    float*  ptr;      // base of the destination tensor (NHWC, possibly a wider concat buffer)
+    int32_t stride;   // floats per pixel in the destination
+    int32_t off;      // first channel of the slice written
+    int32_t width;    // number of conv output channels stored through this descriptor
+};
+
+// Arguments of the implicit-GEMM convolution (tf.nn.conv2d SAME stride 1 + bias + activator,
+// helper/tf_graph.py:104-153; optional depth_to_space and residual add folded into the store).
+struct ConvArgs {
+    const float* in;          // NHWC source, [n, H, W, in_stride]
+    int32_t in_stride;
+    int32_t in_off;           // first channel of the slice read (multiple of 4)
+    int32_t cin_phys;         // physical channels read (multiple of 4)
+    int32_t n_chunks;         // ceil(cin_phys / KC)
+    const float* wpack;       // [n_tiles][n_chunks][taps * KC * NS] repacked filters
+    const float* bias;        // [n_tiles * NT * 16], zero padded
+    const float* alpha;       // same length (negative slope); ignored unless act == ACT_ALPHA
+    int32_t act;
+    int32_t N, H, W;          // batch and spatial size the conv runs at
+    int32_t tiles_x, tiles_y;
+    OutDesc out0, out1;       // conv channel c goes to out0 when c < split, else to out1 (c - split)
+    int32_t split;            // multiple of 16; >= padded channel count when there is one output
+    int32_t ps;               // depth_to_space block (1 = none), tf_graph.py:248
+    int32_t ps_c;             // channels after depth_to_space
+    int32_t vec4;             // 1: every 4-channel group may be stored as one float4
+    const float* res;         // optional residual ([n, H*ps, W*ps, res_stride]) added before the store
+    int32_t res_stride;
+};
+
+struct ConvShape {            // kernel variant picked by the plan
+    int ks, mt, nt, kc;
+};
+
+// Geometry helpers shared by the weight packer (host) and the kernels (device).
+__host__ __device__ constexpr int conv_ns(int nt) { return (nt & 1) ? nt * 16 : nt * 16 + 16; }
+__host__ __device__ constexpr int conv_plane_stride(int halo_pixels) {
+    // smallest value >= halo_pixels that is 16 (mod 32): two k-planes read by one 32-lane LDS group
+    // then fall on disjoint bank halves
+    return ((halo_pixels + 15) / 32) * 32 + 16;
+}
+
+// Picks (mt, nt, kc) for a conv with `cout_padded16` output channels per tile.
+ConvShape conv_pick_shape(int ks, int nt);
+size_t conv_lds_bytes(const ConvShape& s);
+// One-time: raise the dynamic-LDS limit of every instantiated kernel. Returns hipSuccess or error.
+hipError_t conv_init_kernels();
+hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream);
+
+// First layer: 3x3 (or 1x1) conv from ONE input channel, direct form (write-bound).
+struct Cin1Args {
+    const float* x;           // [n, H, W] (channel stride 1)
+    const float* w;           // [ks*ks][cs] zero padded
+    const float* bias;        // [cs]
+    const float* alpha;       // [cs]
+    int32_t act;
+    int32_t ks;
+    int32_t N, H, W;
+    int32_t cs;               // stored channels (multiple of 4)
+    OutDesc out;
+};
+hipError_t cin1_launch(const Cin1Args& a, hipStream_t stream);
+
+// Depthwise k x k SAME, channel multiplier 1 (first half of tf.nn.separable_conv2d, tf_graph.py:161).
+struct DwArgs {
+    const float* in; int32_t in_stride, in_off;
+    const int32_t* chan_map;  // [cin] logical -> physical channel (relative to in_off), device memory
+    const float* w;           // [ks*ks][cin]
+    int32_t ks, cin, cout_phys;
+    int32_t N, H, W;
+    float* out; int32_t out_stride;   // writes channels [0, cout_phys): logical then zero padding
+};
+hipError_t depthwise_launch(const DwArgs& a, hipStream_t stream);
+
+}  // namespace dcscn

@@ -1,0 +1,177 @@
+/*
+ * dcscn.h -- C ABI of the MI355X-native DCSCN forward pass (libdcscn_hip.so).
+ *
+ * The reference (jiny2001/dcscn-super-resolution) has no FFI of its own: its forward pass is a
+ * TensorFlow session call.  This header is the drop-in seam for that call; every entry point cites
+ * the reference interface it stands in for (file:line into the reference tree).
+ *
+ *   reference                                                      this library
+ *   ------------------------------------------------------------   ---------------------------
+ *   SuperResolution.__init__ + build_graph  (DCSCN.py:29-106,222)   dcscn_create
+ *   tf.train.Saver.restore by variable name (tf_graph.py:263-280)   dcscn_set_tensor (+ tensor_info)
+ *   init_all_variables / first sess.run     (tf_graph.py:73-75)     dcscn_finalize
+ *   sess.run(self.y_, {x, x2, dropout:1.0, is_training:0})          dcscn_forward / dcscn_forward_device
+ *                                           (DCSCN.py:565-569,575-578)
+ *   self-ensemble loop of do()              (DCSCN.py:559-573)      dcscn_forward_ensemble
+ *   logging "Complexity" / layer list       (DCSCN.py:331-332)      dcscn_layer_info
+ *   sess.close()                                                    dcscn_destroy
+ *
+ * Conventions: plain C types only; all image tensors are dense NHWC float32 with C == 1
+ * (x: [n, h, w, 1], x2 / y: [n, s*h, s*w, 1], s = scale).  Weights are passed exactly as the
+ * checkpoint stores them (conv filters HWIO) under the checkpoint's variable names.  Every call
+ * returns a dcscn_status; nothing aborts the process.  A handle owns one device, one HIP stream and
+ * its workspace, and must not be used from two threads at once.  There is no CPU fallback: on a
+ * machine without a usable HIP device dcscn_create fails with DCSCN_ERR_HIP.
+ */
+#ifndef DCSCN_H_
+#define DCSCN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCSCN_ABI_VERSION 1
+#define DCSCN_MAX_NAME 128
+
+typedef struct dcscn_ctx* dcscn_handle;
+
+typedef enum dcscn_status {
+    DCSCN_OK = 0,
+    DCSCN_ERR_INVALID_ARG = 1,    /* null pointer, bad size, bad enum */
+    DCSCN_ERR_UNSUPPORTED = 2,    /* a flag combination the HIP path does not implement */
+    DCSCN_ERR_MISSING_TENSOR = 3, /* finalize(): a variable the graph needs was never set
+                                     (reference: Saver.restore raises NotFoundError) */
+    DCSCN_ERR_SHAPE = 4,          /* set_tensor(): unknown name or shape mismatch */
+    DCSCN_ERR_HIP = 5,            /* HIP runtime error / no device */
+    DCSCN_ERR_STATE = 6,          /* call order violated (e.g. forward before finalize) */
+    DCSCN_ERR_NOMEM = 7
+} dcscn_status;
+
+/* helper/tf_graph.py:77-102 build_activator */
+typedef enum dcscn_activator {
+    DCSCN_ACT_NONE = 0,
+    DCSCN_ACT_PRELU = 1,
+    DCSCN_ACT_RELU = 2,
+    DCSCN_ACT_LEAKY_RELU = 3,
+    DCSCN_ACT_SIGMOID = 4,
+    DCSCN_ACT_TANH = 5,
+    DCSCN_ACT_SELU = 6
+} dcscn_activator;
+
+/* Model flags of helper/args.py:17-36 as consumed by DCSCN.py:33-48 and build_graph. */
+typedef struct dcscn_config {
+    int32_t struct_size;            /* = sizeof(dcscn_config), ABI guard */
+    int32_t scale;                  /* 2, 3 or 4 */
+    int32_t layers;                 /* feature-extraction layers */
+    int32_t filters;
+    int32_t min_filters;
+    double  filters_decay_gamma;
+    int32_t cnn_size;               /* 3 (1 is accepted) */
+    int32_t use_nin;
+    int32_t nin_filters;            /* A1 */
+    int32_t nin_filters2;           /* B1, B2 */
+    int32_t reconstruct_layers;     /* max(flag, 1) applied inside, DCSCN.py:42 */
+    int32_t reconstruct_filters;
+    int32_t activator;              /* dcscn_activator */
+    int32_t pixel_shuffler;         /* must be 1 (transposed-conv upsampler not implemented) */
+    int32_t pixel_shuffler_filters; /* 0 = same as input channels */
+    int32_t depthwise_separable;
+    int32_t channels;               /* must be 1 */
+    int32_t legacy_no_c;            /* 1: graph of the shipped dcscn_L2_* checkpoints (use_nin=0 and
+                                       no 1x1 "C" layer between H_concat and the upsampler) */
+    int32_t batch_norm;             /* must be 0 */
+    int32_t reserved[8];
+} dcscn_config;
+
+/* One conv layer of the graph, in build order (CNN1.., A1, B1, B2 | C, Up-PS.., R-CNN..). */
+typedef struct dcscn_layer_info {
+    char    name[DCSCN_MAX_NAME];   /* checkpoint scope, e.g. "CNN3", "Up-PS/Up-PS_CNN" */
+    int32_t kernel_size;
+    int32_t in_channels;
+    int32_t out_channels;
+    int32_t depthwise_separable;
+    int32_t has_bias;
+    int32_t activator;
+    int32_t resolution;             /* pixels per LR pixel along one axis where the conv runs */
+    int64_t macs_per_lr_pixel;      /* multiply-accumulates per LR pixel */
+} dcscn_layer_info;
+
+/* Library / ABI version (DCSCN_ABI_VERSION). */
+int dcscn_abi_version(void);
+
+/* Message of the last failing call on this thread that had no usable handle (e.g. dcscn_create). */
+const char* dcscn_last_global_error(void);
+
+/* Number of visible HIP devices, or a negative dcscn_status. */
+int dcscn_device_count(void);
+
+/* Feature-extraction filter schedule of DCSCN.py:232,240-244; writes `layers` ints. */
+int dcscn_filter_schedule(int layers, int filters, int min_filters, double gamma, int32_t* out);
+
+/* Build the graph for `cfg` on HIP device `device` (SuperResolution.__init__ + build_graph). */
+int dcscn_create(const dcscn_config* cfg, int device, dcscn_handle* out);
+
+/* Variables the graph expects, in checkpoint naming (tf_graph.py:117-216). shape has 4 slots. */
+int dcscn_num_tensors(dcscn_handle h);
+int dcscn_tensor_info(dcscn_handle h, int index, char* name, int name_capacity, int64_t* shape, int* rank);
+
+/* Copy one variable in (Saver.restore); `shape`/`rank` must match the graph. Host memory. */
+int dcscn_set_tensor(dcscn_handle h, const char* name, const float* data, const int64_t* shape, int rank);
+
+/* Repack weights for the MFMA kernels and upload them.  All variables must have been set. */
+int dcscn_finalize(dcscn_handle h);
+
+/* Conv layers of the graph (for logging / FLOP accounting). */
+int dcscn_num_layers(dcscn_handle h);
+int dcscn_layer_info_get(dcscn_handle h, int index, dcscn_layer_info* out);
+
+/* Kernel launches one forward pass is made of, in stream order (valid after dcscn_finalize).
+ * A launch covers one graph layer, or two when they are fused (A1 and B1 share one GEMM). */
+typedef struct dcscn_op_info {
+    char    name[DCSCN_MAX_NAME];   /* e.g. "CNN2", "B1+A1", "CNN3/depthwise" */
+    char    kernel[32];             /* "conv_igemm", "conv_cin1", "depthwise" */
+    int32_t kernel_size;
+    int32_t in_channels;            /* logical */
+    int32_t out_channels;           /* logical */
+    int32_t resolution;
+    int32_t mt, nt, kc, n_tiles;    /* conv_igemm variant (0 for the other kernels) */
+    int64_t macs_per_lr_pixel;      /* algorithmic multiply-accumulates per LR pixel */
+    int64_t bytes_per_lr_pixel;     /* algorithmic activation bytes read + written per LR pixel */
+} dcscn_op_info;
+int dcscn_num_ops(dcscn_handle h);
+int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
+
+/* Tunables: "sub_batch_pixels" (LR pixels processed per pass through the layer chain),
+ * "profile" (1: time every layer with HIP events, read back with dcscn_get_profile). */
+int dcscn_set_option(dcscn_handle h, const char* key, int64_t value);
+
+/* Forward pass on host buffers: H2D, kernels, D2H, synchronous. */
+int dcscn_forward(dcscn_handle h, const float* x, const float* x2, float* y, int n, int height, int width);
+
+/* Forward pass on device buffers, enqueued on `stream` (a hipStream_t, NULL = the handle's own
+ * stream) without synchronising.  Workspace growth (first call / larger shape) does synchronise. */
+int dcscn_forward_device(dcscn_handle h, const float* x, const float* x2, float* y,
+                         int n, int height, int width, void* stream);
+
+/* do() with self_ensemble = n_ensemble in [1, 8] for ONE image (DCSCN.py:559-573): the flipped /
+ * rotated copies (utilty.py:595-617) run as two batches on the device; the mean over copies is
+ * accumulated in float64 in the reference's order.  x: [h, w], x2: [s*h, s*w], y: float64 [s*h, s*w]. */
+int dcscn_forward_ensemble(dcscn_handle h, const float* x, const float* x2, double* y,
+                           int height, int width, int n_ensemble);
+
+/* Per-launch (dcscn_op_info order) device milliseconds of the most recent forward (profile option
+ * on), summed over sub-batches; `ms` receives min(capacity, num_ops) entries.  Synchronises. */
+int dcscn_get_profile(dcscn_handle h, double* ms, int capacity);
+
+/* Bytes of device workspace currently held. */
+int64_t dcscn_workspace_bytes(dcscn_handle h);
+
+const char* dcscn_last_error(dcscn_handle h);
+int dcscn_destroy(dcscn_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCSCN_H_ */

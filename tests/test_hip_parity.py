@@ -1,0 +1,135 @@
+"""Parity of the HIP forward pass (through the C ABI) against the CPU oracle.
+
+Tolerances are the ones BASELINE.json's north_star states: max-abs pixel error <= 1e-4 on the 0-255
+scale against the float64 oracle (the reference itself is float32 TensorFlow).
+"""
+import numpy as np
+import pytest
+
+from conftest import CONFIGS, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+
+MAX_ABS_TOL = 1e-4
+
+
+def _engine(cfg, weights):
+    from dcscn_amd import engine
+    eng = engine.Engine(cfg, device=0)
+    eng.load_weights(weights)
+    return eng
+
+
+def _check(oracle, name, overrides, n, h, w, seed=0, sub_batch_pixels=None):
+    cfg = oracle.make_config(**overrides)
+    weights = oracle.synthetic_weights(cfg, seed=seed)
+    x, x2 = synthetic_batch(n, h, w, cfg["scale"], seed=seed + 1)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with _engine(cfg, weights) as eng:
+        if sub_batch_pixels:
+            eng.set_option("sub_batch_pixels", sub_batch_pixels)
+        y = eng.forward(x, x2)
+    assert y.shape == ref.shape and y.dtype == np.float32
+    err = float(np.max(np.abs(y.astype(np.float64) - ref)))
+    scale = float(np.max(np.abs(ref)))
+    print("%s n=%d %dx%d max|y|=%.1f max-abs err %.3g" % (name, n, h, w, scale, err))
+    assert np.isfinite(y).all()
+    assert err <= MAX_ABS_TOL, "%s: max-abs error %.3g > %.1g" % (name, err, MAX_ABS_TOL)
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_config_48x48(oracle, name):
+    """Every BASELINE config (and every shipped-checkpoint topology) on 48x48 patches."""
+    n = 2 if "L12" in name or "L8" in name else 3
+    _check(oracle, name, CONFIGS[name], n, 48, 48)
+
+
+@pytest.mark.parametrize("hw", [(1, 1), (5, 7), (16, 16), (17, 33), (31, 9), (50, 20)])
+def test_ragged_sizes(oracle, hw):
+    """Image sizes that are not multiples of the 8x16 / 16x16 pixel tiles, down to a single pixel."""
+    _check(oracle, "L7_F32to8_x2", CONFIGS["L7_F32to8_x2"], 2, hw[0], hw[1])
+    _check(oracle, "odd-channels", dict(layers=4, filters=37, min_filters=13, nin_filters=21, nin_filters2=10), 1, hw[0], hw[1])
+
+
+def test_sub_batching_is_transparent(oracle):
+    """Splitting the batch into passes must not change a single bit (no cross-image coupling)."""
+    cfg = oracle.make_config(**CONFIGS["L7_F32to8_x2"])
+    weights = oracle.synthetic_weights(cfg, seed=3)
+    x, x2 = synthetic_batch(5, 24, 40, 2, seed=4)
+    with _engine(cfg, weights) as eng:
+        full = eng.forward(x, x2)
+        eng.set_option("sub_batch_pixels", 2 * 24 * 40)
+        parts = eng.forward(x, x2)
+        eng.set_option("sub_batch_pixels", 1)
+        single = eng.forward(x, x2)
+    assert np.array_equal(full, parts) and np.array_equal(full, single)
+
+
+@pytest.mark.parametrize("variant", [
+    dict(use_nin=False, layers=3, filters=20, min_filters=8),                      # 1x1 "C" layer path
+    dict(layers=3, filters=24, min_filters=8, reconstruct_layers=3, reconstruct_filters=12),
+    dict(layers=3, filters=16, min_filters=8, scale=3),
+    dict(layers=3, filters=16, min_filters=8, scale=3, pixel_shuffler_filters=1),
+    dict(layers=3, filters=16, min_filters=8, scale=4, pixel_shuffler_filters=6),
+    dict(layers=3, filters=16, min_filters=8, activator="relu"),
+    dict(layers=3, filters=16, min_filters=8, activator="leaky_relu"),
+    dict(layers=3, filters=16, min_filters=0),
+    dict(layers=2, filters=8, min_filters=8, cnn_size=1),
+    dict(layers=3, filters=16, min_filters=8, depthwise_separable=True, scale=2),
+    dict(layers=3, filters=16, min_filters=8, depthwise_separable=True, use_nin=False, scale=3),
+])
+def test_flag_surface(oracle, variant):
+    _check(oracle, str(variant), variant, 2, 20, 28)
+
+
+@pytest.mark.parametrize("act", ["sigmoid", "tanh", "selu"])
+def test_transcendental_activators(oracle, act):
+    # device expf/tanhf are not correctly rounded: looser bound, still far below one grey level
+    cfg = oracle.make_config(layers=3, filters=16, min_filters=8, activator=act)
+    weights = oracle.synthetic_weights(cfg, seed=0)
+    x, x2 = synthetic_batch(2, 20, 28, 2, seed=1)
+    x = x / 255.0
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with _engine(cfg, weights) as eng:
+        y = eng.forward(x, x2)
+    assert float(np.max(np.abs(y - ref))) <= 1e-3
+
+
+@pytest.mark.parametrize("n_ens", [1, 2, 5, 8])
+def test_self_ensemble(oracle, n_ens):
+    """do() with self_ensemble (DCSCN.py:559-573): batched on the device, float64 mean in reference order."""
+    cfg = oracle.make_config(**CONFIGS["L7_F32to8_x2"])
+    weights = oracle.synthetic_weights(cfg, seed=5)
+    x, x2 = synthetic_batch(1, 18, 30, 2, seed=6)
+    ref = oracle.do(cfg, weights, x[0], x2[0], self_ensemble=n_ens, dtype=np.float64)
+    with _engine(cfg, weights) as eng:
+        y = eng.forward_ensemble(x[0], x2[0], n_ens)
+    assert y.dtype == np.float64 and y.shape == ref.shape
+    assert float(np.max(np.abs(y - ref))) <= MAX_ABS_TOL
+
+
+def test_errors_are_reported_not_fatal(oracle):
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS["L2_F4to4_x2"])
+    weights = oracle.synthetic_weights(cfg)
+    eng = engine.Engine(cfg)
+    x, x2 = synthetic_batch(1, 8, 8, 2)
+    with pytest.raises(engine.EngineError) as e:      # forward before finalize
+        eng.forward(x, x2)
+    assert e.value.status == 6
+    with pytest.raises(engine.EngineError) as e:      # unknown variable
+        eng.set_tensor("nope/conv_W", np.zeros((3, 3, 1, 4), np.float32))
+    assert e.value.status == 4
+    with pytest.raises(engine.EngineError) as e:      # wrong shape
+        eng.set_tensor("CNN1/conv_W", np.zeros((3, 3, 1, 5), np.float32))
+    assert e.value.status == 4
+    with pytest.raises(engine.EngineError) as e:      # finalize with variables missing
+        eng.finalize()
+    assert e.value.status == 3
+    eng.load_weights(weights)
+    assert eng.forward(x, x2).shape == (1, 16, 16, 1)
+    eng.close()
+    with pytest.raises(engine.EngineError):
+        engine.Engine(oracle.make_config(pixel_shuffler=False))
+    with pytest.raises(engine.EngineError):
+        engine.Engine(dict(scale=5))
