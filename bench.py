@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X-native DCSCN forward pass (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the default
+``dcscn_L12_F196to48_NIN_A64_PS`` x2 graph on 1024 synthetic 48x48 Y-channel patches PER GPU
+(weak scaling: independent patches shard across ranks, no data-path collective).  A step is one
+forward pass of the whole per-GPU batch with x / x2 already resident in HBM and y left in HBM.
+Weights are seeded synthetic (the trained L12 blobs are not shipped with the reference).
+
+Rank 0 prints one JSON line: LR Mpixels/s over all GPUs, plus
+  roofline      -- the dominant kernel (3x3 implicit-GEMM conv on f32 MFMA): algorithmic FLOP per
+                   step / its summed launch time measured with HIP events inside the timed steps
+  cpu_baseline  -- the float32 torch-CPU restatement of the same graph (oracle/cpu_path_torch.py;
+                   TensorFlow is not installable) timed on the host cores on a bounded sample.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PATCH = 48
+PATCHES_PER_GPU = 1024
+MODEL_FLAGS = dict()          # defaults of helper/args.py = dcscn_L12_F196to48_NIN_A64_PS_R1F32, scale 2
+MODEL_NAME = "dcscn_L12_F196to48_NIN_A64_PS"
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--patches", type=int, default=PATCHES_PER_GPU, help="48x48 patches per GPU")
+    ap.add_argument("--sub-batch-pixels", type=int, default=0, help="override the engine's pass size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ops", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="patches in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X; there is no CPU fallback for the HIP path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from dcscn_amd import engine
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import dcscn_oracle as O          # synthetic-weight generator + CPU baseline only
+
+    cfg = O.make_config(**MODEL_FLAGS)
+    weights = O.synthetic_weights(cfg, seed=0)
+    eng = engine.Engine(cfg, device=local_rank)
+    eng.load_weights(weights)
+    if args.sub_batch_pixels:
+        eng.set_option("sub_batch_pixels", args.sub_batch_pixels)
+
+    n, s = args.patches, cfg["scale"]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    x = torch.rand((n, PATCH, PATCH, 1), device="cuda", generator=gen) * 255.0
+    x2 = torch.rand((n, PATCH * s, PATCH * s, 1), device="cuda", generator=gen) * 255.0
+    y = torch.empty_like(x2)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        eng.forward_device(x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, PATCH, PATCH, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.set_option("profile", 1)      # HIP events around every launch, on the launch stream
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    per_op_ms = eng.profile()         # averaged over the timed steps
+    eng.set_option("profile", 0)
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not bool(torch.isfinite(y).all().item()):
+        raise SystemExit("non-finite output")
+
+    if rank == 0:
+        ops = eng.ops()
+        lr_pixels = n * PATCH * PATCH
+        # dominant kernel: the 3x3 implicit-GEMM conv launches (CNN2..12, B2, Up-PS)
+        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] == "conv_igemm" and o["kernel_size"] == 3
+               and o["out_channels"] > 1]
+        dom_flop = sum(2.0 * o["macs_per_lr_pixel"] for o, _ in dom) * lr_pixels
+        dom_ms = sum(ms for _, ms in dom)
+        achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        total_macs = sum(o["macs_per_lr_pixel"] for o in ops)
+        kernel_ms = sum(per_op_ms)
+        per_kernel = {}
+        for o, ms in zip(ops, per_op_ms):
+            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] == "conv_igemm" else "")
+            per_kernel[key] = per_kernel.get(key, 0.0) + ms
+        if args.ops:
+            for o, ms in zip(ops, per_op_ms):
+                fl = 2.0 * o["macs_per_lr_pixel"] * lr_pixels
+                by = o["bytes_per_lr_pixel"] * lr_pixels
+                print("%-22s %-11s k%d %4d->%-4d res%d mt%d nt%-2d kc%-2d tiles%d  %8.3f ms  %7.2f TFLOP/s  %7.1f GB/s"
+                      % (o["name"], o["kernel"], o["kernel_size"], o["in_channels"], o["out_channels"], o["resolution"],
+                         o["mt"], o["nt"], o["kc"], o["n_tiles"], ms, fl / (ms * 1e-3) / 1e12 if ms else 0,
+                         by / (ms * 1e-3) / 1e9 if ms else 0), file=sys.stderr)
+        result = {
+            "metric": "LR Mpixels/sec at 48x48 patches, L12_F196to48 x2",
+            "value": round(world * lr_pixels * args.steps / elapsed / 1e6, 4),
+            "unit": "LR Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (uniform 0-255 Y patches, seeded He-init weights; trained L12 blobs are not shipped)",
+            "config": {
+                "workload": "%s x2 forward, %d 48x48 Y patches per GPU (BASELINE.json configs[2])" % (MODEL_NAME, n),
+                "patches_per_gpu": n,
+                "global_patches": n * world,
+                "parallelism": "image-shard x%d, no collective" % world,
+                "flop_per_lr_pixel": 2 * total_macs,
+            },
+            "roofline": {
+                "kernel": "conv_igemm 3x3 (v_mfma_f32_16x16x4_f32), %d launches/pass" % len(dom),
+                "bound": "mfma",
+                "achieved": round(achieved, 3),
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None,
+                "algorithmic_flop_per_step": dom_flop,
+                "kernel_ms_per_step": round(dom_ms, 4),
+            },
+            "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_kernel.items())},
+            "whole_net_tflops": round(2.0 * total_macs * lr_pixels / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import cpu_path_torch as T
+            cs = min(args.cpu_sample, n)
+            xs = x[:cs].cpu().numpy()
+            x2s = x2[:cs].cpu().numpy()
+            sec, threads, ycpu = T.time_cpu_path(cfg, weights, xs, x2s, reps=2)
+            dev_err = float(np.max(np.abs(ycpu - y[:cs].cpu().numpy())))
+            result["cpu_baseline"] = {
+                "value": round(cs * PATCH * PATCH / sec / 1e6, 5),
+                "unit": "LR Mpix/s",
+                "cores": threads,
+                "kind": "port",
+                "sample": "%d of the %d patches, float32 torch-CPU (oneDNN) restatement of the reference graph "
+                          "(TensorFlow not installable), best of 2 after 1 warm-up per thread setting, %.2f s/forward" % (cs, n, sec),
+                "max_abs_diff_vs_hip": dev_err,
+            }
+        print(json.dumps(result), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,10 +122,14 @@ struct dcscn_ctx {
     size_t io_x_cap = 0, io_y_cap = 0;
     std::vector<void*> device_allocs;
 
-    int64_t sub_batch_pixels = 128 * 48 * 48;
+    // LR pixels per pass through the layer chain.  Big passes keep >= ~10 rounds of workgroups per
+    // launch on the 256 CUs (a 128-patch pass left a 10-25 % tail); bounded by workspace_budget.
+    int64_t sub_batch_pixels = 4 << 20;
+    int64_t workspace_budget = (int64_t)48 << 30;
     bool profile = false;
-    std::vector<hipEvent_t> ev;              // 2 per op per sub-batch slot
-    int ev_batches = 0;
+    std::vector<hipEvent_t> ev;              // event pool: 2 per launch
+    size_t ev_used = 0;                      // events recorded since the last dcscn_get_profile
+    int ev_forwards = 0;                     // forwards recorded since the last dcscn_get_profile
     std::vector<double> prof_ms;
 };
 
@@ -653,7 +657,10 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     if (!x || !x2 || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t per_image = (int64_t)H * W;
-    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(n, h->sub_batch_pixels / per_image));
+    int64_t ws_per_lr_pixel = 0;      // workspace bytes per LR pixel
+    for (const WsBuf& b : h->bufs) ws_per_lr_pixel += (int64_t)b.res * b.res * b.stride * (int64_t)sizeof(float);
+    const int64_t pass_pixels = std::min<int64_t>(h->sub_batch_pixels, h->workspace_budget / std::max<int64_t>(ws_per_lr_pixel, 1));
+    int nb = (int)std::max<int64_t>(1, std::min<int64_t>(n, pass_pixels / per_image));
     int rc = ensure_workspace(h, nb, H, W);
     if (rc) return rc;
     if (stream != h->stream) {
@@ -663,16 +670,18 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     const int s = h->cfg.scale;
     const int batches = (n + nb - 1) / nb;
     const int nops = (int)h->ops.size();
+    // profile mode: one event pair per launch, kept for every forward since the last dcscn_get_profile
+    size_t ev_base = 0;
     if (h->profile) {
-        const size_t need = (size_t)batches * nops * 2;
+        ev_base = h->ev_used;
+        const size_t need = ev_base + (size_t)batches * nops * 2;
         while (h->ev.size() < need) {
             hipEvent_t e;
             HIP_TRY(h, hipEventCreate(&e));
             h->ev.push_back(e);
         }
-        h->ev_batches = batches;
-    } else {
-        h->ev_batches = 0;
+        h->ev_used = need;
+        h->ev_forwards += 1;
     }
     for (int b = 0; b < batches; ++b) {
         const int b0 = b * nb;
@@ -681,10 +690,10 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         const float* x2b = x2 + (size_t)b0 * H * s * W * s;
         float* yb = y + (size_t)b0 * H * s * W * s;
         for (int i = 0; i < nops; ++i) {
-            if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[((size_t)b * nops + i) * 2], stream));
+            if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[ev_base + ((size_t)b * nops + i) * 2], stream));
             rc = launch_op(h, h->ops[i], cnt, H, W, xb, x2b, yb, stream);
             if (rc) return rc;
-            if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[((size_t)b * nops + i) * 2 + 1], stream));
+            if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[ev_base + ((size_t)b * nops + i) * 2 + 1], stream));
         }
     }
     return DCSCN_OK;
@@ -879,6 +888,11 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
         h->sub_batch_pixels = value;
         return DCSCN_OK;
     }
+    if (!strcmp(key, "workspace_budget_bytes")) {
+        if (value < 1) return fail(h, DCSCN_ERR_INVALID_ARG, "workspace_budget_bytes must be >= 1");
+        h->workspace_budget = value;
+        return DCSCN_OK;
+    }
     if (!strcmp(key, "profile")) {
         h->profile = value != 0;
         return DCSCN_OK;
@@ -989,15 +1003,20 @@ int dcscn_get_profile(dcscn_handle h, double* ms, int capacity) {
     if (!ms || capacity < 0) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_get_profile: bad argument");
     const int nops = (int)h->ops.size();
     std::vector<double> acc(nops, 0.0);
-    if (h->ev_batches > 0) {
+    const int forwards = h->ev_forwards;
+    if (h->ev_used > 0) {
         HIP_TRY(h, hipDeviceSynchronize());
-        for (int b = 0; b < h->ev_batches; ++b)
-            for (int i = 0; i < nops; ++i) {
-                float t = 0.0f;
-                HIP_TRY(h, hipEventElapsedTime(&t, h->ev[((size_t)b * nops + i) * 2], h->ev[((size_t)b * nops + i) * 2 + 1]));
-                acc[i] += t;
-            }
+        const size_t launches = h->ev_used / 2;
+        for (size_t l = 0; l < launches; ++l) {
+            float t = 0.0f;
+            HIP_TRY(h, hipEventElapsedTime(&t, h->ev[2 * l], h->ev[2 * l + 1]));
+            acc[l % nops] += t;
+        }
     }
+    h->ev_used = 0;
+    h->ev_forwards = 0;
+    if (forwards > 1)
+        for (double& v : acc) v /= forwards;
     for (int i = 0; i < std::min(capacity, nops); ++i) ms[i] = acc[i];
     return DCSCN_OK;
 }

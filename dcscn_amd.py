@@ -13,6 +13,6 @@ if _root not in sys.path:
     sys.path.insert(0, _root)
 
 _pkg = importlib.import_module("dcscn-super-resolution_amd")
-for _sub in ("build", "ckpt", "engine"):
+for _sub in ("build", "ckpt", "engine", "flags", "imaging", "shard", "model"):
     importlib.import_module("dcscn-super-resolution_amd." + _sub)
 sys.modules[__name__] = _pkg

@@ -143,8 +143,9 @@ typedef struct dcscn_op_info {
 int dcscn_num_ops(dcscn_handle h);
 int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
 
-/* Tunables: "sub_batch_pixels" (LR pixels processed per pass through the layer chain),
- * "profile" (1: time every layer with HIP events, read back with dcscn_get_profile). */
+/* Tunables: "sub_batch_pixels" (LR pixels processed per pass through the layer chain, default 4 Mi),
+ * "workspace_budget_bytes" (caps the pass size so the activation workspace stays below it, default
+ * 48 GiB), "profile" (1: time every launch with HIP events, read back with dcscn_get_profile). */
 int dcscn_set_option(dcscn_handle h, const char* key, int64_t value);
 
 /* Forward pass on host buffers: H2D, kernels, D2H, synchronous. */
@@ -161,8 +162,9 @@ int dcscn_forward_device(dcscn_handle h, const float* x, const float* x2, float*
 int dcscn_forward_ensemble(dcscn_handle h, const float* x, const float* x2, double* y,
                            int height, int width, int n_ensemble);
 
-/* Per-launch (dcscn_op_info order) device milliseconds of the most recent forward (profile option
- * on), summed over sub-batches; `ms` receives min(capacity, num_ops) entries.  Synchronises. */
+/* Per-launch (dcscn_op_info order) device milliseconds, summed over sub-batches and averaged over
+ * the forwards run with the profile option on since the previous call (which this call resets);
+ * `ms` receives min(capacity, num_ops) entries.  Synchronises the device. */
 int dcscn_get_profile(dcscn_handle h, double* ms, int capacity);
 
 /* Bytes of device workspace currently held. */

@@ -1,0 +1,231 @@
+"""Host-side pieces that need no GPU: checkpoint reader, flag surface, imaging helpers, model naming,
+the C ABI's symbol table and its loud failure without a device."""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from conftest import GOLDEN, ROOT
+
+
+# ---- TF checkpoint reader -------------------------------------------------------------------------
+def test_checkpoint_reader_reads_shipped_bundle():
+    from dcscn_amd import ckpt
+    prefix = os.path.join(GOLDEN, "models", "dcscn_L2_F4to4_PS_R1F4.ckpt")
+    names = dict(ckpt.list_variables(prefix))
+    assert names["CNN1/conv_W"] == (3, 3, 1, 4) and names["Up-PS/Up-PS_CNN/conv_W"] == (3, 3, 8, 32)
+    assert any(ckpt.is_optimizer_slot(n) for n in names)            # Adam slots are in the file ...
+    tensors = ckpt.load_checkpoint(prefix)
+    assert not any(ckpt.is_optimizer_slot(n) for n in tensors)      # ... and dropped by default
+    golden = np.load(os.path.join(GOLDEN, "weights_L2_x2.npz"))
+    assert set(golden.files) == set(tensors)
+    for k in golden.files:
+        assert np.array_equal(golden[k], tensors[k]) and tensors[k].dtype == np.float32
+
+
+def test_checkpoint_reader_rejects_garbage(tmp_path):
+    from dcscn_amd import ckpt
+    bad = tmp_path / "x.ckpt.index"
+    bad.write_bytes(b"\x00" * 100)
+    with pytest.raises(ckpt.CheckpointError):
+        ckpt.read_index(str(bad))
+    short = tmp_path / "y.ckpt.index"
+    short.write_bytes(b"abc")
+    with pytest.raises(ckpt.CheckpointError):
+        ckpt.read_index(str(short))
+    # index present, data shard missing (the reference's L8 / L12 checkpoints ship like this)
+    src = os.path.join(GOLDEN, "models", "dcscn_L2_F4to4_PS_R1F4.ckpt.index")
+    lone = tmp_path / "z.ckpt.index"
+    lone.write_bytes(open(src, "rb").read())
+    assert not ckpt.has_data(str(tmp_path / "z.ckpt"))
+    with pytest.raises(ckpt.CheckpointError):
+        ckpt.load_checkpoint(str(tmp_path / "z.ckpt"))
+
+
+# ---- flags ----------------------------------------------------------------------------------------
+def _fresh_flags():
+    from dcscn_amd import flags
+    fv = flags.FlagValues()
+    flags.DEFINE_integer("scale", 2, "", flag_values=fv)
+    flags.DEFINE_float("gamma", 1.5, "", flag_values=fv)
+    flags.DEFINE_boolean("use_nin", True, "", flag_values=fv)
+    flags.DEFINE_boolean("ds", False, "", flag_values=fv)
+    flags.DEFINE_string("file", "image.jpg", "", flag_values=fv)
+    return flags, fv
+
+
+def test_flag_syntax():
+    flags, fv = _fresh_flags()
+    assert (fv.scale, fv.gamma, fv.use_nin, fv.ds, fv.file) == (2, 1.5, True, False, "image.jpg")
+    rest = fv(["prog", "--scale=4", "--gamma", "1.2", "--nouse_nin", "--ds", "-file=a.png", "extra"])
+    assert rest == ["prog", "extra"]
+    assert (fv.scale, fv.gamma, fv.use_nin, fv.ds, fv.file) == (4, 1.2, False, True, "a.png")
+    fv.reset()
+    fv(["prog", "--use_nin=false", "--ds=True", "--", "--scale=9"])
+    assert (fv.use_nin, fv.ds, fv.scale) == (False, True, 2)
+    with pytest.raises(flags.FlagError):
+        fv(["prog", "--unknown=1"])
+    with pytest.raises(flags.FlagError):
+        fv(["prog", "--scale=abc"])
+    with pytest.raises(flags.FlagError):
+        fv(["prog", "--scale"])
+    fv.scale = 3
+    assert fv.scale == 3 and fv.flag_values_dict()["scale"] == 3
+
+
+def test_reference_flag_surface():
+    """Every flag of the reference's helper/args.py:17-98 with its default."""
+    from helper import args
+    expect = dict(scale=2, layers=12, filters=196, min_filters=48, filters_decay_gamma=1.5, use_nin=True,
+                  nin_filters=64, nin_filters2=32, cnn_size=3, reconstruct_layers=1, reconstruct_filters=32,
+                  dropout_rate=0.8, activator="prelu", pixel_shuffler=True, pixel_shuffler_filters=0,
+                  self_ensemble=8, batch_norm=False, depthwise_separable=False, bicubic_init=True, clipping_norm=5.0,
+                  initializer="he", weight_dev=0.01, l2_decay=0.0001, optimizer="adam", beta1=0.9, beta2=0.999,
+                  epsilon=1e-8, momentum=0.9, batch_num=20, batch_image_size=48, stride_size=0,
+                  training_images=24000, use_l1_loss=False, initial_lr=0.002, lr_decay=0.5, lr_decay_epoch=9,
+                  end_lr=2e-5, dataset="bsd200", test_dataset="set5", tests=1, do_benchmark=False, max_value=255.0,
+                  channels=1, psnr_calc_border_size=-1, build_batch=False, checkpoint_dir="models",
+                  graph_dir="graphs", data_dir="data", batch_dir="batch_data", output_dir="output",
+                  tf_log_dir="tf_log", log_filename="log.txt", model_name="", load_model_name="",
+                  initialize_tf_log=True, enable_log=True, save_weights=True, save_images=False, save_images_num=20,
+                  save_meta_data=False, gpu_device_id=0, frozenInference=False,
+                  frozen_graph_path="./model_to_freeze/frozen_model_optimized.pb")
+    defaults = {n: args.FLAGS._flags[n].default for n in args.FLAGS}
+    for name, value in expect.items():
+        assert name in defaults, name
+        assert defaults[name] == value and type(defaults[name]) is type(value), name
+
+
+# ---- model naming (selects the checkpoint file) -----------------------------------------------------
+class _F(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _flags(**over):
+    from helper import args
+    d = {n: args.FLAGS._flags[n].default for n in args.FLAGS}
+    d.update(over)
+    d["log_filename"] = ""
+    return _F(d)
+
+
+def test_model_names_select_the_shipped_checkpoints(tmp_path):
+    from dcscn_amd.model import SuperResolution
+    ck = str(tmp_path / "models")
+    L7 = dict(layers=7, filters=32, min_filters=8, filters_decay_gamma=1.2, nin_filters=24, nin_filters2=8,
+              reconstruct_layers=0, self_ensemble=1, pixel_shuffler_filters=1, checkpoint_dir=ck)
+    cases = [
+        (dict(checkpoint_dir=ck), "dcscn_L12_F196to48_NIN_A64_PS_R1F32"),
+        (dict(scale=3, checkpoint_dir=ck), "dcscn_L12_F196to48_Sc3_NIN_A64_PS_R1F32"),
+        (dict(layers=8, filters=96, scale=4, checkpoint_dir=ck), "dcscn_L8_F96to48_Sc4_NIN_A64_PS_R1F32"),
+        (L7, "dcscn_L7_F32to8_G1.20_NIN_A24_B8_PS_R1F32"),
+        (dict(L7, scale=4, depthwise_separable=True), "dcscn_L7_F32to8_G1.20_Sc4_NIN_A24_B8_PS_DS_R1F32"),
+        (dict(layers=2, filters=4, min_filters=4, use_nin=False, reconstruct_filters=4, checkpoint_dir=ck),
+         "dcscn_L2_F4to4_PS_R1F4"),
+    ]
+    for over, name in cases:
+        assert SuperResolution(_flags(**over)).name == name
+    assert SuperResolution(_flags(checkpoint_dir=ck), model_name="abc").name == "dcscn_abc"
+
+
+# ---- imaging ----------------------------------------------------------------------------------------
+def test_imaging_helpers():
+    from dcscn_amd import imaging as util
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (10, 14, 3)).astype(np.uint8)
+    for t in range(8):
+        assert np.array_equal(util.flip(util.flip(img, t), t, invert=True), img)
+    assert util.set_image_alignment(img, 4).shape == (8, 12, 3)
+    y = util.convert_rgb_to_y(img)
+    ycc = util.convert_rgb_to_ycbcr(img)
+    assert y.dtype == np.float64 and np.allclose(y[:, :, 0], ycc[:, :, 0])
+    back = util.convert_ycbcr_to_rgb(ycc)
+    assert np.max(np.abs(back - img)) < 0.01
+    lr = util.resize_image_by_pil(y, 0.5)
+    assert lr.shape == (5, 7, 1) and lr.dtype == np.float32
+    assert util.resize_image_by_pil(img, 2).shape == (20, 28, 3)
+    a = rng.uniform(0, 255, (40, 40, 1))
+    psnr, ssim = util.compute_psnr_and_ssim(a, a, border_size=2)
+    assert psnr == float("inf") and abs(ssim - 1.0) < 1e-12
+    b = a + rng.normal(0, 5, a.shape)
+    psnr, ssim = util.compute_psnr_and_ssim(a, b, border_size=2)
+    assert 30 < psnr < 40 and 0.5 < ssim < 1.0
+    assert util.compute_psnr_and_ssim(a, b[:-1]) is None
+
+
+def test_bicubic_goldens_through_the_host_glue(oracle):
+    """evaluate_bicubic's recipe with the package's own helpers reproduces the oracle's numbers."""
+    from dcscn_amd import imaging as util
+    from dcscn_amd.model import build_input_image
+    with open(os.path.join(GOLDEN, "goldens.json")) as f:
+        g = json.load(f)
+    for s in (2, 3, 4):
+        for i in (1, 4):
+            img = util.set_image_alignment(util.load_image(os.path.join(GOLDEN, "set5", g["files"][i]),
+                                                           print_console=False), s)
+            lr = build_input_image(img, channels=1, scale=s, alignment=s, convert_ycbcr=True)
+            bic = util.resize_image_by_pil(lr, s)
+            psnr, _ = util.compute_psnr_and_ssim(util.convert_rgb_to_y(img), bic, border_size=s)
+            assert abs(psnr - g["bicubic"]["x%d" % s][i]) < 1e-9
+
+
+def test_save_and_load_roundtrip(tmp_path):
+    from dcscn_amd import imaging as util
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (6, 9, 3)).astype(np.uint8)
+    grey = rng.uniform(0, 255, (6, 9, 1))
+    util.save_image(str(tmp_path / "a" / "rgb.png"), rgb, print_console=False)
+    util.save_image(str(tmp_path / "grey.png"), grey, print_console=False)
+    assert np.array_equal(util.load_image(str(tmp_path / "a" / "rgb.png"), print_console=False), rgb)
+    assert np.array_equal(util.load_image(str(tmp_path / "grey.png"), print_console=False)[:, :, 0],
+                          grey[:, :, 0].astype(np.uint8))
+    with pytest.raises(util.LoadError):
+        util.load_image(str(tmp_path / "missing.png"))
+
+
+# ---- C ABI ------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    from dcscn_amd import build, engine
+    build.build()                                        # no-op when up to date; hipcc cross-compiles on CPU
+    header = open(os.path.join(ROOT, "include", "dcscn.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(dcscn_[a-z_]+)\s*\(", header))
+    assert declared == set(engine.EXPORTED_SYMBOLS)
+    lib = engine.load_library()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.dcscn_abi_version() == engine.ABI_VERSION
+    import ctypes
+    assert ctypes.sizeof(engine.Config) == 120    # dcscn_config: 5 x i32, pad, f64, 13 x i32, 8 reserved, tail pad
+    # host-side helper that needs no device
+    assert engine.filter_schedule(12, 196, 48, 1.5) == [196, 166, 148, 133, 120, 108, 97, 86, 76, 66, 57, 48]
+    assert engine.filter_schedule(7, 32, 8, 1.2) == [32, 26, 22, 18, 14, 11, 8]
+
+
+def test_filter_schedule_matches_python_for_many_flags(oracle):
+    from dcscn_amd import engine
+    for layers in (1, 2, 3, 7, 12, 20):
+        for filters, minf in ((196, 48), (96, 48), (32, 8), (64, 64), (10, 0), (8, 32)):
+            for gamma in (1.0, 1.2, 1.5, 2.0, 0.7):
+                if layers == 1 and minf != 0:
+                    continue      # the reference divides by (layers - 1)
+                want = oracle.filter_schedule(layers, filters, min(filters, minf), gamma)
+                assert engine.filter_schedule(layers, filters, minf, gamma) == want
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product path must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from dcscn_amd import engine
+    with pytest.raises(engine.EngineError) as e:
+        engine.Engine(dict())
+    assert e.value.status == 5
+    src = open(os.path.join(ROOT, "dcscn-super-resolution_amd", "model.py")).read() + \
+        open(os.path.join(ROOT, "dcscn-super-resolution_amd", "engine.py")).read()
+    assert "oracle" not in src
