@@ -44,7 +44,7 @@ inline int pad4(int c) { return (c + 3) & ~3; }
 inline int pad16(int c) { return (c + 15) & ~15; }
 
 enum { EXT_X = -1, EXT_X2 = -2, EXT_Y = -3 };
-enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2 };
+enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2, OP_COUT1 = 3 };
 
 struct TensorSpec {
     std::string name;
@@ -315,7 +315,9 @@ void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_nam
         op.macs = r2 * (int64_t)ks * ks * cout;
         op.bytes = 4 * r2 + out_bytes;
     } else {
-        op.kind = OP_CONV;
+        const bool to_y = cout == 1 && dst.buf == EXT_Y && !bias && activator == DCSCN_ACT_NONE &&
+                          (size_t)ks * ks * (src.cin_phys + 328) * sizeof(float) <= 64 * 1024;
+        op.kind = to_y ? OP_COUT1 : OP_CONV;
         op.ks = ks;
         op.cin = cin;
         op.in_buf = src.buf;
@@ -323,7 +325,7 @@ void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_nam
         op.cin_phys = src.cin_phys;
         op.chan_map = src.map;
         op.macs = li.macs_per_lr_pixel;
-        op.bytes = 4 * r2 * src.cin_phys + out_bytes;
+        op.bytes = 4 * r2 * src.cin_phys + out_bytes + (dst.residual ? 4 * r2 : 0);
     }
     h->ops.push_back(op);
 }
@@ -500,6 +502,15 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     }
 
     const int taps = op.ks * op.ks;
+    if (op.kind == OP_COUT1) {
+        const ColSeg& s = op.segs[0];
+        const TensorSpec& tw = h->tensors[s.w];             // [k, k, cin, 1]
+        const int cin = (int)op.chan_map.size();
+        std::vector<float> w((size_t)taps * op.cin_phys, 0.0f);
+        for (int t = 0; t < taps; ++t)
+            for (int ci = 0; ci < cin; ++ci) w[(size_t)t * op.cin_phys + op.chan_map[ci]] = tw.data[(size_t)t * cin + ci];
+        return upload(h, w.data(), w.size() * sizeof(float), (void**)&op.d_w);
+    }
     if (op.kind == OP_CIN1) {
         const ColSeg& s = op.segs[0];
         const int cs = op.out_width[0];
@@ -603,6 +614,23 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.out = buf_ptr(h, op.out_buf[0]);
         a.out_stride = pad4(op.cin);
         HIP_TRY(h, depthwise_launch(a, stream));
+        return DCSCN_OK;
+    }
+    if (op.kind == OP_COUT1) {
+        Cout1Args a{};
+        a.in = buf_ptr(h, op.in_buf);
+        a.in_stride = h->bufs[op.in_buf].stride;
+        a.in_off = op.in_off;
+        a.cin_phys = op.cin_phys;
+        a.w = op.d_w;
+        a.bias = 0.0f;
+        a.ks = op.ks;
+        a.N = nb; a.H = Hr; a.W = Wr;
+        a.out = y;
+        a.out_stride = 1;
+        a.res = op.residual ? x2 : nullptr;
+        a.res_stride = 1;
+        HIP_TRY(h, cout1_launch(a, stream));
         return DCSCN_OK;
     }
     if (op.kind == OP_CIN1) {
@@ -867,7 +895,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     const Op& op = h->ops[index];
     memset(out, 0, sizeof *out);
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
-    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? "conv_igemm" : op.kind == OP_CIN1 ? "conv_cin1" : "depthwise");
+    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? "conv_igemm" : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
     out->out_channels = op.cout;

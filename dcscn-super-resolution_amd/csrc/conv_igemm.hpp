@@ -1,0 +1,297 @@
+// conv_igemm: the implicit-GEMM convolution kernel template (see kernels.hip for the overview).
+// Shared by kernels.hip (the shipped variant table) and tools/conv_tune.hip (variant exploration).
+#pragma once
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace dcscn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// activator (helper/tf_graph.py:77-102)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float activate1(float v, float alpha, int act) {
+    switch (act) {
+        case ACT_ALPHA:   return v > 0.0f ? v : alpha * v;   // == relu(v) + alpha*(v-|v|)*0.5 in f32
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        case ACT_TANH:    return tanhf(v);
+        case ACT_SELU:    return 1.0507009873554805f * (v > 0.0f ? v : 1.6732632423543772f * (expf(v) - 1.0f));
+        default:          return v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM convolution on v_mfma_f32_16x16x4_f32
+//
+// GEMM view per tap: D[cout][pixel] += W[cout][cin] * X[cin][pixel]; the MFMA "A" operand (rows) is
+// the filter, the "B" operand (columns) is 16 consecutive pixels of one image row, so a lane ends up
+// holding 4 consecutive output channels of one pixel = one float4 NHWC store.
+//
+// Workgroup = 4 waves, pixel tile = (4*MT) rows x 16 columns, all NT*16 output channels of its
+// channel tile.  Wave w owns rows [w*MT, (w+1)*MT).  K is walked in chunks of KC input channels;
+// for each chunk the input tile (with a 1-pixel zero halo for 3x3: SAME padding is re-applied at every
+// layer) and the KS*KS*KC*NT*16 filter block are staged in LDS.  The global loads of chunk c+1 are
+// issued before the MFMAs of chunk c (register prefetch); DB selects whether they are then written to a
+// second LDS buffer (one barrier per chunk) or to the same buffer after a second barrier (half the LDS,
+// more workgroups per CU -- the shipped choice).
+//
+// LDS image, per buffer:
+//   A: [KC][PS]        input, channel-major planes of the halo tile (PS = 16 mod 32)
+//   B: [taps][KC][NS]  filters (NS = 16 mod 32)
+// Both operands are read with ds_read_b32 where lanes 0-15 walk 16 consecutive floats and lanes 16-31
+// the same 16 floats of the next k-plane; the plane strides put those on the other half of the 32
+// banks, so every read is conflict free.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int MT, int NT, int KC>
+struct ConvGeom {
+    static constexpr int TAPS = KS * KS;
+    static constexpr int HALO = KS / 2;
+    static constexpr int TH = 4 * MT;
+    static constexpr int TW = 16;
+    static constexpr int HTH = TH + 2 * HALO;
+    static constexpr int HTW = TW + 2 * HALO;
+    static constexpr int HP = HTH * HTW;
+    static constexpr int PS = conv_plane_stride(HP);
+    static constexpr int NS = conv_ns(NT);
+    static constexpr int KQ = KC / 4;
+    static constexpr int A_FLOATS = KC * PS;
+    static constexpr int B_FLOATS = TAPS * KC * NS;
+    static constexpr int BUF = A_FLOATS + B_FLOATS;
+    static constexpr int A_ITEMS = HP * KQ;
+    static constexpr int A_LOADS = (A_ITEMS + 255) / 256;
+    static constexpr int B_VEC = B_FLOATS / 4;
+    static constexpr int B_LOADS = (B_VEC + 255) / 256;
+    static_assert(KC % 4 == 0, "KC must be a multiple of the MFMA k extent");
+    static_assert(BUF % 4 == 0 && A_FLOATS % 4 == 0, "LDS carve must stay 16-byte aligned");
+};
+
+// Compile-time loop: the index reaches the body as a constant, so register arrays (accumulators,
+// operand fragments, staging registers) are only ever indexed statically and stay in VGPRs whatever
+// the optimiser's unrolling heuristics decide (a runtime-indexed f32x4 array lands in scratch).
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+#define DCSCN_INL __attribute__((always_inline))
+
+template <int KS, int MT, int NT, int KC, bool DB = true, int WPS = 2>
+__global__ __launch_bounds__(256, WPS) void conv_igemm(const ConvArgs a) {
+    using G = ConvGeom<KS, MT, NT, KC>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15;   // pixel column within the 16-wide segment / filter row within a 16-tile
+    const int lk = lane >> 4;   // k index within the 4-deep MFMA step / channel quad of the result
+
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int ntile = blockIdx.y;
+    const int y0 = ty * G::TH;
+    const int x0 = tx * G::TW;
+    const int H = a.H, W = a.W;
+
+    const float* in_img = a.in + (size_t)img * H * W * a.in_stride + a.in_off;
+
+    // ---- staging descriptors (constant over the K loop) ----
+    const float* a_src[G::A_LOADS];
+    int a_dst[G::A_LOADS];
+    int a_c4[G::A_LOADS];
+    bool a_item[G::A_LOADS], a_inb[G::A_LOADS];
+    static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
+        constexpr int i = decltype(i_)::value;
+        const int item = tid + 256 * i;
+        const int hp = item / G::KQ;
+        const int q = item - hp * G::KQ;
+        const int hy = hp / G::HTW;
+        const int hx = hp - hy * G::HTW;
+        const int gy = y0 + hy - G::HALO;
+        const int gx = x0 + hx - G::HALO;
+        a_item[i] = item < G::A_ITEMS;
+        a_inb[i] = a_item[i] && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        a_c4[i] = 4 * q;
+        a_dst[i] = 4 * q * G::PS + hp;
+        a_src[i] = in_img + ((size_t)(a_inb[i] ? gy : 0) * W + (a_inb[i] ? gx : 0)) * a.in_stride + 4 * q;
+    });
+    const float* b_src = a.wpack + (size_t)ntile * a.n_chunks * G::B_FLOATS + 4 * tid;
+
+    f32x4 areg[G::A_LOADS];
+    f32x4 breg[G::B_LOADS];
+
+    auto load_chunk = [&](int chunk) DCSCN_INL {
+        const int c0 = chunk * KC;
+        static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (a_inb[i] && c0 + a_c4[i] < a.cin_phys) v = *reinterpret_cast<const f32x4*>(a_src[i] + c0);
+            areg[i] = v;
+        });
+        const float* bs = b_src + (size_t)chunk * G::B_FLOATS;
+        static_for<0, G::B_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            if (i < G::B_LOADS - 1 || tid + 256 * i < G::B_VEC)
+                breg[i] = *reinterpret_cast<const f32x4*>(bs + 1024 * i);
+        });
+    };
+    auto store_chunk = [&](float* buf) DCSCN_INL {
+        static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            if (a_item[i]) {
+                float* d = buf + a_dst[i];
+                d[0] = areg[i].x;
+                d[G::PS] = areg[i].y;
+                d[2 * G::PS] = areg[i].z;
+                d[3 * G::PS] = areg[i].w;
+            }
+        });
+        float* bd = buf + G::A_FLOATS + 4 * tid;
+        static_for<0, G::B_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            if (i < G::B_LOADS - 1 || tid + 256 * i < G::B_VEC)
+                *reinterpret_cast<f32x4*>(bd + 1024 * i) = breg[i];
+        });
+    };
+
+    f32x4 acc[MT][NT];
+    static_for<0, MT>([&](auto m_) DCSCN_INL {
+        static_for<0, NT>([&](auto n_) DCSCN_INL {
+            acc[decltype(m_)::value][decltype(n_)::value] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        });
+    });
+
+    const int a_lane = lk * G::PS + wave * MT * G::HTW + lj;
+    const int b_lane = G::A_FLOATS + lk * G::NS + lj;
+
+    auto compute = [&](const float* buf) DCSCN_INL {
+        const float* As = buf + a_lane;
+        const float* Bs = buf + b_lane;
+        static_for<0, G::TAPS>([&](auto tap_) DCSCN_INL {
+            constexpr int tap = decltype(tap_)::value;
+            constexpr int dy = tap / KS, dx = tap % KS;
+            static_for<0, G::KQ>([&](auto ks_) DCSCN_INL {
+                constexpr int ks = decltype(ks_)::value;
+                float xv[MT], wv[NT];
+                static_for<0, MT>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    xv[m] = As[(ks * 4) * G::PS + (m + dy) * G::HTW + dx];
+                });
+                static_for<0, NT>([&](auto n_) DCSCN_INL {
+                    constexpr int n = decltype(n_)::value;
+                    wv[n] = Bs[(tap * KC + ks * 4) * G::NS + n * 16];
+                });
+                static_for<0, MT>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    static_for<0, NT>([&](auto n_) DCSCN_INL {
+                        constexpr int n = decltype(n_)::value;
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[n], xv[m], acc[m][n], 0, 0, 0);
+                    });
+                });
+            });
+        });
+    };
+
+    // ---- K loop ----
+    if constexpr (DB) {
+        // LDS double buffered: one barrier per chunk
+        load_chunk(0);
+        store_chunk(smem);
+        __syncthreads();
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            float* cur = smem + (chunk & 1) * G::BUF;
+            float* nxt = smem + ((chunk + 1) & 1) * G::BUF;
+            const bool more = chunk + 1 < a.n_chunks;
+            if (more) load_chunk(chunk + 1);
+            compute(cur);
+            if (more) store_chunk(nxt);
+            __syncthreads();
+        }
+    } else {
+        // one LDS buffer, next chunk prefetched into registers during the MFMAs: half the LDS, so more
+        // workgroups per CU cover each other's staging phases; two barriers per chunk
+        load_chunk(0);
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            store_chunk(smem);
+            __syncthreads();
+            if (chunk + 1 < a.n_chunks) load_chunk(chunk + 1);
+            compute(smem);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias, activator, (depth_to_space), (residual), store ----
+    const int gx = x0 + lj;
+    const int gy0 = y0 + wave * MT;
+    const int cbase = ntile * NT * 16;
+    const int act = a.act;
+    if (gx >= W) return;
+    static_for<0, NT>([&](auto n_) DCSCN_INL {
+        constexpr int n = decltype(n_)::value;
+        const int c = cbase + n * 16 + 4 * lk;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c);
+        f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (act == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(a.alpha + c);
+        const bool first = c < a.split;
+        float* optr = first ? a.out0.ptr : a.out1.ptr;
+        const int ostride = first ? a.out0.stride : a.out1.stride;
+        const int ooff = first ? a.out0.off : a.out1.off;
+        const int owidth = first ? a.out0.width : a.out1.width;
+        const int cc = first ? c : c - a.split;
+        // destination of channel cc+r: pixel (gy*ps + ay[r], gx*ps + bx[r]), channel ch[r]
+        int ch[4], ay[4], bx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ccr = cc + r;
+            if (a.ps == 1) {
+                ch[r] = ccr; ay[r] = 0; bx[r] = 0;
+            } else {
+                const int sub = ccr / a.ps_c;
+                ch[r] = ccr - sub * a.ps_c;
+                ay[r] = sub / a.ps;
+                bx[r] = sub - ay[r] * a.ps;
+            }
+        }
+        const size_t orow = (size_t)W * a.ps;
+        static_for<0, MT>([&](auto m_) DCSCN_INL {
+            constexpr int m = decltype(m_)::value;
+            const int gy = gy0 + m;
+            if (gy < H) {
+                f32x4 v = acc[m][n] + bv;
+                v.x = activate1(v.x, av.x, act);
+                v.y = activate1(v.y, av.y, act);
+                v.z = activate1(v.z, av.z, act);
+                v.w = activate1(v.w, av.w, act);
+                const size_t prow = ((size_t)img * H + gy) * a.ps;
+                if (a.vec4) {
+                    if (cc < owidth) {
+                        const size_t pix = (prow + ay[0]) * orow + (size_t)gx * a.ps + bx[0];
+                        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + pix * a.res_stride + ch[0]);
+                        *reinterpret_cast<f32x4*>(optr + pix * ostride + ooff + ch[0]) = v;
+                    }
+                } else {
+                    const float vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (cc + r < owidth) {
+                            const size_t pix = (prow + ay[r]) * orow + (size_t)gx * a.ps + bx[r];
+                            float out = vr[r];
+                            if (a.res) out += a.res[pix * a.res_stride + ch[r]];
+                            optr[pix * ostride + ooff + ch[r]] = out;
+                        }
+                    }
+                }
+            }
+        });
+    });
+}
+
+
+}  // namespace dcscn

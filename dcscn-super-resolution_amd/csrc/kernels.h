@@ -72,6 +72,19 @@ struct Cin1Args {
 };
 hipError_t cin1_launch(const Cin1Args& a, hipStream_t stream);
 
+// Last reconstruction conv: k x k conv to ONE output channel, no activator, plus the residual add
+// (R-CNN + x2, DCSCN.py:318-325).  HBM bound (AI 4.5): reads the input once, writes one float per pixel.
+struct Cout1Args {
+    const float* in; int32_t in_stride, in_off, cin_phys;
+    const float* w;           // [ks*ks][cin_phys], zero padded, physical channel order
+    float bias;
+    int32_t ks;
+    int32_t N, H, W;
+    float* out; int32_t out_stride;
+    const float* res; int32_t res_stride;   // optional residual, same pixel indexing as out
+};
+hipError_t cout1_launch(const Cout1Args& a, hipStream_t stream);
+
 // Depthwise k x k SAME, channel multiplier 1 (first half of tf.nn.separable_conv2d, tf_graph.py:161).
 struct DwArgs {
     const float* in; int32_t in_stride, in_off;

@@ -131,7 +131,7 @@ int dcscn_layer_info_get(dcscn_handle h, int index, dcscn_layer_info* out);
  * A launch covers one graph layer, or two when they are fused (A1 and B1 share one GEMM). */
 typedef struct dcscn_op_info {
     char    name[DCSCN_MAX_NAME];   /* e.g. "CNN2", "B1+A1", "CNN3/depthwise" */
-    char    kernel[32];             /* "conv_igemm", "conv_cin1", "depthwise" */
+    char    kernel[32];             /* "conv_igemm", "conv_cin1", "conv_cout1", "depthwise" */
     int32_t kernel_size;
     int32_t in_channels;            /* logical */
     int32_t out_channels;           /* logical */
