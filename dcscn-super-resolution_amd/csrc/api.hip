@@ -78,7 +78,9 @@ struct Op {
     std::vector<int> chan_map;      // logical input channel -> physical channel relative to in_off
     // filter sources
     std::vector<ColSeg> segs;
-    int dw_w = -1;                  // depthwise filter tensor (OP_DW)
+    int dw_w = -1;                  // depthwise filter tensor (OP_DW, fused-depthwise OP_CONV, OP_COUT1 of a separable conv)
+    int dwk = 0;                    // fused depthwise kernel size of an OP_CONV (0 = plain conv)
+    float out_scale = 1.0f;         // OP_COUT1: pointwise scalar of a separable 1->1 conv
     // output
     int out_buf[2] = {EXT_Y, EXT_Y}, out_off[2] = {0, 0}, out_width[2] = {0, 0};
     int split = 1 << 30;
@@ -95,6 +97,7 @@ struct Op {
     float* d_bias = nullptr;
     float* d_alpha = nullptr;
     int32_t* d_map = nullptr;
+    float* d_dww = nullptr;
 };
 
 }  // namespace
@@ -276,8 +279,35 @@ void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_nam
               !dst.residual;
     const int64_t out_bytes = 4 * r2 * dst.width;
 
-    if (ds) {
-        // depthwise half -> DW scratch (logical channel order, zero padded to 4)
+    if (ds && src.buf >= 0 && cin == 1 && cout == 1 && dst.buf == EXT_Y && !bias && activator == DCSCN_ACT_NONE) {
+        // separable 1 -> 1 conv (R-CNN of the c-DCSCN DS models): depthwise sum, times the pointwise
+        // scalar, plus the residual -- one launch of the single-output kernel
+        op.kind = OP_COUT1;
+        op.ks = ks;
+        op.cin = 1;
+        op.in_buf = src.buf;
+        op.in_off = src.off;
+        op.cin_phys = src.cin_phys;
+        op.chan_map = src.map;
+        op.dw_w = t_dw;
+        op.macs = li.macs_per_lr_pixel;
+        op.bytes = 4 * r2 * src.cin_phys + out_bytes + (dst.residual ? 4 * r2 : 0);
+    } else if (ds && src.buf >= 0) {
+        // depthwise half fused into the staging of the pointwise GEMM: its output never touches HBM
+        op.kind = OP_CONV;
+        op.ks = 1;
+        op.dwk = ks;
+        op.dw_w = t_dw;
+        op.cin = cin;
+        op.in_buf = src.buf;
+        op.in_off = src.off;
+        op.cin_phys = src.cin_phys;
+        op.chan_map = src.map;
+        op.macs = li.macs_per_lr_pixel;
+        op.bytes = 4 * r2 * src.cin_phys + out_bytes + (dst.residual ? 4 * r2 : 0);
+    } else if (ds) {
+        // first layer (reads the 1-channel external input): depthwise half -> DW scratch (logical channel
+        // order, zero padded to 4), then the pointwise GEMM
         if (*dw_buf < 0) *dw_buf = new_buf(h, 4, 1);
         Op dw;
         dw.kind = OP_DW;
@@ -504,7 +534,9 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     const int taps = op.ks * op.ks;
     if (op.kind == OP_COUT1) {
         const ColSeg& s = op.segs[0];
-        const TensorSpec& tw = h->tensors[s.w];             // [k, k, cin, 1]
+        const bool separable = op.dw_w >= 0;
+        const TensorSpec& tw = h->tensors[separable ? op.dw_w : s.w];   // [k, k, cin, 1]
+        if (separable) op.out_scale = h->tensors[s.w].data[0];       // pointwise [1, 1, 1, 1]
         const int cin = (int)op.chan_map.size();
         std::vector<float> w((size_t)taps * op.cin_phys, 0.0f);
         for (int t = 0; t < taps; ++t)
@@ -531,9 +563,19 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     int ctot = 0;
     for (const ColSeg& s : op.segs) ctot = std::max(ctot, s.dst + s.cout);
     const int tiles16 = (ctot + 15) / 16;
-    op.n_tiles = (tiles16 + 12) / 13;
+    const int max_nt = op.dwk ? conv_max_fused_dw_nt() : 13;
+    op.n_tiles = (tiles16 + max_nt - 1) / max_nt;
     const int nt = (tiles16 + op.n_tiles - 1) / op.n_tiles;
-    op.shape = conv_pick_shape(op.ks, nt);
+    op.shape = conv_pick_shape(op.ks, nt, op.dwk);
+    if (op.dwk) {
+        const TensorSpec& td = h->tensors[op.dw_w];          // [k, k, cin, 1] -> [taps][cin_phys] physical
+        const int dtaps = op.dwk * op.dwk, cin = (int)op.chan_map.size();
+        std::vector<float> dww((size_t)dtaps * op.cin_phys, 0.0f);
+        for (int t = 0; t < dtaps; ++t)
+            for (int ci = 0; ci < cin; ++ci) dww[(size_t)t * op.cin_phys + op.chan_map[ci]] = td.data[(size_t)t * cin + ci];
+        int rc0 = upload(h, dww.data(), dww.size() * sizeof(float), (void**)&op.d_dww);
+        if (rc0) return rc0;
+    }
     op.ctot = op.n_tiles * nt * 16;
     const int kc = op.shape.kc;
     op.n_chunks = (op.cin_phys + kc - 1) / kc;
@@ -623,6 +665,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.in_off = op.in_off;
         a.cin_phys = op.cin_phys;
         a.w = op.d_w;
+        a.scale = op.out_scale;
         a.bias = 0.0f;
         a.ks = op.ks;
         a.N = nb; a.H = Hr; a.W = Wr;
@@ -674,6 +717,8 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     a.vec4 = op.vec4 ? 1 : 0;
     a.res = op.residual ? x2 : nullptr;
     a.res_stride = 1;
+    a.dww = op.d_dww;
+    a.dwk = op.dwk;
     HIP_TRY(h, conv_launch(op.shape, a, op.n_tiles, stream));
     return DCSCN_OK;
 }

@@ -79,8 +79,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 #define DCSCN_INL __attribute__((always_inline))
 
-template <int KS, int MT, int NT, int KC, bool DB = true, int WPS = 2>
+template <int KS, int MT, int NT, int KC, bool DB = true, int WPS = 2, int DWK = 0>
 __global__ __launch_bounds__(256, WPS) void conv_igemm(const ConvArgs a) {
+    static_assert(DWK == 0 || KS == 1, "the fused depthwise stage feeds a pointwise (1x1) GEMM");
     using G = ConvGeom<KS, MT, NT, KC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256, WPS) void conv_igemm(const ConvArgs a) {
     const float* a_src[G::A_LOADS];
     int a_dst[G::A_LOADS];
     int a_c4[G::A_LOADS];
+    int a_gy[G::A_LOADS], a_gx[G::A_LOADS];
     bool a_item[G::A_LOADS], a_inb[G::A_LOADS];
     static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
         constexpr int i = decltype(i_)::value;
@@ -119,6 +121,8 @@ __global__ __launch_bounds__(256, WPS) void conv_igemm(const ConvArgs a) {
         a_item[i] = item < G::A_ITEMS;
         a_inb[i] = a_item[i] && gy >= 0 && gy < H && gx >= 0 && gx < W;
         a_c4[i] = 4 * q;
+        a_gy[i] = gy;
+        a_gx[i] = gx;
         a_dst[i] = 4 * q * G::PS + hp;
         a_src[i] = in_img + ((size_t)(a_inb[i] ? gy : 0) * W + (a_inb[i] ? gx : 0)) * a.in_stride + 4 * q;
     });
@@ -132,7 +136,28 @@ __global__ __launch_bounds__(256, WPS) void conv_igemm(const ConvArgs a) {
         static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
             f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (a_inb[i] && c0 + a_c4[i] < a.cin_phys) v = *reinterpret_cast<const f32x4*>(a_src[i] + c0);
+            if (a_inb[i] && c0 + a_c4[i] < a.cin_phys) {
+                if constexpr (DWK == 0) {
+                    v = *reinterpret_cast<const f32x4*>(a_src[i] + c0);
+                } else {
+                    // depthwise DWK x DWK, SAME zero padding, on the fly (tf_graph.py:161)
+                    const float* wq = a.dww + c0 + a_c4[i];
+#pragma unroll
+                    for (int dy = 0; dy < DWK; ++dy) {
+                        const int yy = a_gy[i] + dy - DWK / 2;
+#pragma unroll
+                        for (int dx = 0; dx < DWK; ++dx) {
+                            const int xx = a_gx[i] + dx - DWK / 2;
+                            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                                const f32x4 xin = *reinterpret_cast<const f32x4*>(
+                                    in_img + ((size_t)yy * W + xx) * a.in_stride + a_c4[i] + c0);
+                                const f32x4 wt = *reinterpret_cast<const f32x4*>(wq + (dy * DWK + dx) * a.cin_phys);
+                                v += xin * wt;
+                            }
+                        }
+                    }
+                }
+            }
             areg[i] = v;
         });
         const float* bs = b_src + (size_t)chunk * G::B_FLOATS;

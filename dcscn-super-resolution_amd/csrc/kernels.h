@@ -37,10 +37,15 @@ struct ConvArgs {
     int32_t vec4;             // 1: every 4-channel group may be stored as one float4
     const float* res;         // optional residual ([n, H*ps, W*ps, res_stride]) added before the store
     int32_t res_stride;
+    // fused depthwise stage of tf.nn.separable_conv2d (1x1 kernels only): the staged input element is
+    // sum_t in(p + o_t)[c] * dww[t][c] instead of in(p)[c]
+    const float* dww;         // [dwk*dwk][cin_phys], physical channel order, zero padded (or nullptr)
+    int32_t dwk;              // depthwise kernel size: 0 (none), 1 or 3
 };
 
 struct ConvShape {            // kernel variant picked by the plan
     int ks, mt, nt, kc;
+    int dwk = 0;              // fused depthwise kernel size (ks == 1 only)
 };
 
 // Geometry helpers shared by the weight packer (host) and the kernels (device).
@@ -52,11 +57,13 @@ __host__ __device__ constexpr int conv_plane_stride(int halo_pixels) {
 }
 
 // Picks (mt, nt, kc) for a conv with `cout_padded16` output channels per tile.
-ConvShape conv_pick_shape(int ks, int nt);
+ConvShape conv_pick_shape(int ks, int nt, int dwk = 0);
 size_t conv_lds_bytes(const ConvShape& s);
 // One-time: raise the dynamic-LDS limit of every instantiated kernel. Returns hipSuccess or error.
 hipError_t conv_init_kernels();
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream);
+// widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
+int conv_max_fused_dw_nt();
 
 // First layer: 3x3 (or 1x1) conv from ONE input channel, direct form (write-bound).
 struct Cin1Args {
@@ -77,6 +84,7 @@ hipError_t cin1_launch(const Cin1Args& a, hipStream_t stream);
 struct Cout1Args {
     const float* in; int32_t in_stride, in_off, cin_phys;
     const float* w;           // [ks*ks][cin_phys], zero padded, physical channel order
+    float scale;              // out = scale * conv + bias (+ res): the 1->1 pointwise half of a separable conv
     float bias;
     int32_t ks;
     int32_t N, H, W;

@@ -33,7 +33,7 @@ __host__ __device__ constexpr int pick_wps(int ks, int nt) {
 }
 constexpr bool kDoubleBuffer = false;
 
-ConvShape conv_pick_shape(int ks, int nt) { return ConvShape{ks, pick_mt(ks, nt), nt, pick_kc(ks, nt)}; }
+ConvShape conv_pick_shape(int ks, int nt, int dwk) { return ConvShape{ks, pick_mt(ks, nt), nt, pick_kc(ks, nt), dwk}; }
 
 static size_t lds_bytes_for(int ks, int mt, int nt, int kc) {
     const int halo = ks / 2;
@@ -47,12 +47,16 @@ size_t conv_lds_bytes(const ConvShape& s) { return lds_bytes_for(s.ks, s.mt, s.n
 #define DCSCN_FOR_NT(X, KS) \
     X(KS, 1) X(KS, 2) X(KS, 3) X(KS, 4) X(KS, 5) X(KS, 6) X(KS, 7) X(KS, 8) X(KS, 9) X(KS, 10) X(KS, 11) X(KS, 12) X(KS, 13)
 
-template <int KS, int NT>
+template <int KS, int NT, int DWK = 0>
 struct Variant {
     static constexpr int MT = pick_mt(KS, NT), KC = pick_kc(KS, NT), WPS = pick_wps(KS, NT);
-    static constexpr auto kernel = &conv_igemm<KS, MT, NT, KC, kDoubleBuffer, WPS>;
+    static constexpr auto kernel = &conv_igemm<KS, MT, NT, KC, kDoubleBuffer, WPS, DWK>;
     static size_t lds() { return lds_bytes_for(KS, MT, NT, KC); }
 };
+// the fused-depthwise pointwise kernels carry more staging state: keep them at the same occupancy target
+// but only for the channel-tile widths separable models use (<= 8 tiles of 16)
+#define DCSCN_FOR_NT_DW(X, DWK) X(1, 1, DWK) X(1, 2, DWK) X(1, 3, DWK) X(1, 4, DWK) X(1, 5, DWK) X(1, 6, DWK) X(1, 7, DWK) X(1, 8, DWK)
+constexpr int kMaxDwNt = 8;
 
 hipError_t conv_init_kernels() {
     hipError_t e;
@@ -66,12 +70,24 @@ hipError_t conv_init_kernels() {
     DCSCN_FOR_NT(X, 1)
     DCSCN_FOR_NT(X, 3)
 #undef X
+#define X(KS, NT, DWK)                                                                     \
+    {                                                                                      \
+        using V = Variant<KS, NT, DWK>;                                                    \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(V::kernel),                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)V::lds()); \
+        if (e != hipSuccess) return e;                                                     \
+    }
+    DCSCN_FOR_NT_DW(X, 1)
+    DCSCN_FOR_NT_DW(X, 3)
+#undef X
     return hipSuccess;
 }
 
-template <int KS, int NT>
+int conv_max_fused_dw_nt() { return kMaxDwNt; }
+
+template <int KS, int NT, int DWK = 0>
 static hipError_t conv_launch_one(const ConvArgs& a, int n_tiles, hipStream_t stream) {
-    using V = Variant<KS, NT>;
+    using V = Variant<KS, NT, DWK>;
     const dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)n_tiles);
     hipLaunchKernelGGL(V::kernel, grid, dim3(256), V::lds(), stream, a);
     return hipGetLastError();
@@ -79,6 +95,16 @@ static hipError_t conv_launch_one(const ConvArgs& a, int n_tiles, hipStream_t st
 
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream) {
     if (s.mt != pick_mt(s.ks, s.nt) || s.kc != pick_kc(s.ks, s.nt)) return hipErrorInvalidValue;
+    if (s.dwk != 0) {
+        if (s.ks != 1 || a.dww == nullptr || a.dwk != s.dwk) return hipErrorInvalidValue;
+        switch (s.dwk * 100 + s.nt) {
+#define X(KS, NT, DWK) case DWK * 100 + NT: return conv_launch_one<KS, NT, DWK>(a, n_tiles, stream);
+            DCSCN_FOR_NT_DW(X, 1)
+            DCSCN_FOR_NT_DW(X, 3)
+#undef X
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (s.ks * 100 + s.nt) {
 #define X(KS, NT) case KS * 100 + NT: return conv_launch_one<KS, NT>(a, n_tiles, stream);
         DCSCN_FOR_NT(X, 1)
@@ -181,7 +207,7 @@ hipError_t cin1_launch(const Cin1Args& a, hipStream_t stream) {
 // share a pixel and walk its channels in 128-byte runs), its taps' partial sums go to LDS, and each
 // thread then gathers the 9 partial sums of its output pixel.  Pixels outside the image contribute 0
 // (SAME zero padding).
-template <int KS>
+template <int KS, int LPP>
 __global__ __launch_bounds__(256) void conv_cout1(const Cout1Args a) {
     constexpr int TAPS = KS * KS, HALO = KS / 2, T = 16, HT = T + 2 * HALO, HP = HT * HT;
     constexpr int SP = (HP + 3) & ~3;
@@ -201,11 +227,11 @@ __global__ __launch_bounds__(256) void conv_cout1(const Cout1Args a) {
     for (int i = tid; i < TAPS * a.cin_phys; i += 256) ws[i] = a.w[i];
     __syncthreads();
 
-    const int sub = tid & 7;          // lane within the 8-lane group of a pixel
-    const int grp = tid >> 3;         // 32 pixels per sweep
+    const int sub = tid % LPP;        // lane within the LPP-lane group that shares a pixel
+    const int grp = tid / LPP;
     const int nq = a.cin_phys >> 2;
     const float* in_img = a.in + (size_t)img * a.H * a.W * a.in_stride + a.in_off;
-    for (int hp = grp; hp < HP; hp += 32) {
+    for (int hp = grp; hp < HP; hp += 256 / LPP) {
         const int hy = hp / HT, hx = hp - hy * HT;
         const int gy = y0 + hy - HALO, gx = x0 + hx - HALO;
         float acc[TAPS];
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_cout1(const Cout1Args a) {
         for (int t = 0; t < TAPS; ++t) acc[t] = 0.0f;
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
             const float* px = in_img + ((size_t)gy * a.W + gx) * a.in_stride;
-            for (int q = sub; q < nq; q += 8) {
+            for (int q = sub; q < nq; q += LPP) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(px + 4 * q);
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
@@ -225,9 +251,9 @@ __global__ __launch_bounds__(256) void conv_cout1(const Cout1Args a) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             float s = acc[t];
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 4);
+            if constexpr (LPP >= 2) s += __shfl_xor(s, 1);
+            if constexpr (LPP >= 4) s += __shfl_xor(s, 2);
+            if constexpr (LPP >= 8) s += __shfl_xor(s, 4);
             if (sub == 0) sp[t * SP + hp] = s;
         }
     }
@@ -236,9 +262,10 @@ __global__ __launch_bounds__(256) void conv_cout1(const Cout1Args a) {
     const int py = tid >> 4, pxl = tid & 15;
     const int gy = y0 + py, gx = x0 + pxl;
     if (gy < a.H && gx < a.W) {
-        float s = a.bias;
+        float s = 0.0f;
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) s += sp[t * SP + (py + t / KS) * HT + pxl + t % KS];
+        s = s * a.scale + a.bias;
         const size_t pix = ((size_t)img * a.H + gy) * a.W + gx;
         if (a.res) s += a.res[pix * a.res_stride];
         a.out[pix * a.out_stride] = s;
@@ -252,9 +279,16 @@ hipError_t cout1_launch(const Cout1Args& a, hipStream_t stream) {
     const size_t lds = (size_t)(a.ks * a.ks * a.cin_phys + a.ks * a.ks * ((hp + 3) & ~3)) * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(a.N * tiles));
-    if (a.ks == 3) hipLaunchKernelGGL(conv_cout1<3>, grid, dim3(256), lds, stream, a);
-    else if (a.ks == 1) hipLaunchKernelGGL(conv_cout1<1>, grid, dim3(256), lds, stream, a);
-    else return hipErrorInvalidValue;
+    const bool narrow = a.cin_phys <= 8;      // one lane per pixel when a pixel is at most two float4
+    if (a.ks == 3) {
+        if (narrow) hipLaunchKernelGGL((conv_cout1<3, 1>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((conv_cout1<3, 8>), grid, dim3(256), lds, stream, a);
+    } else if (a.ks == 1) {
+        if (narrow) hipLaunchKernelGGL((conv_cout1<1, 1>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((conv_cout1<1, 8>), grid, dim3(256), lds, stream, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
