@@ -37,6 +37,29 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dens
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(n_launches):
+    """HBM bytes per step of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/*_pmc_per_dispatch.json: FETCH_SIZE + WRITE_SIZE, KiB, summed over the 3x3
+    conv_igemm dispatches of one forward).  PMC counters cannot be read from inside the process, so
+    this is the offline measurement; None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_dispatch.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            kernels = json.load(f)["kernels"]
+        total = 0.0
+        for name, k in kernels.items():
+            if (name.startswith("conv_igemm<3,") or name.startswith("conv_wino<")) and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+                per_forward = k["dispatches"] / max(k.get("forwards", 4), 1)
+                total += (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 * per_forward
+        return {"bytes_per_step": total, "unit": "B", "source": os.path.basename(files[-1]),
+                "note": "FETCH_SIZE+WRITE_SIZE as reported by rocprofv3 (uncalibrated on gfx950)"} if total else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +69,7 @@ def parse_args():
     ap.add_argument("--sub-batch-pixels", type=int, default=0, help="override the engine's pass size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ops", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--no-winograd", action="store_true", help="keep the 3x3 convs on the direct implicit-GEMM kernel")
     ap.add_argument("--cpu-sample", type=int, default=64, help="patches in the CPU baseline sample")
     return ap.parse_args()
 
@@ -76,7 +100,7 @@ def main():
     cfg = O.make_config(**MODEL_FLAGS)
     weights = O.synthetic_weights(cfg, seed=0)
     eng = engine.Engine(cfg, device=local_rank)
-    eng.load_weights(weights)
+    eng.load_weights(weights, winograd=False if args.no_winograd else None)
     if args.sub_batch_pixels:
         eng.set_option("sub_batch_pixels", args.sub_batch_pixels)
 
@@ -119,16 +143,19 @@ def main():
         ops = eng.ops()
         lr_pixels = n * PATCH * PATCH
         # dominant kernel: the 3x3 implicit-GEMM conv launches (CNN2..12, B2, Up-PS)
-        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] == "conv_igemm" and o["kernel_size"] == 3
-               and o["out_channels"] > 1]
+        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino")
+               and o["kernel_size"] == 3 and o["out_channels"] > 1]
+        dom_kernels = sorted({o["kernel"] for o, _ in dom})
         dom_flop = sum(2.0 * o["macs_per_lr_pixel"] for o, _ in dom) * lr_pixels
         dom_ms = sum(ms for _, ms in dom)
         achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        dom_exec = sum(2.0 * o["executed_macs_per_lr_pixel"] for o, _ in dom) * lr_pixels
+        executed = dom_exec / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         total_macs = sum(o["macs_per_lr_pixel"] for o in ops)
         kernel_ms = sum(per_op_ms)
         per_kernel = {}
         for o, ms in zip(ops, per_op_ms):
-            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] == "conv_igemm" else "")
+            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] in ("conv_igemm", "conv_wino") else "")
             per_kernel[key] = per_kernel.get(key, 0.0) + ms
         if args.ops:
             for o, ms in zip(ops, per_op_ms):
@@ -159,14 +186,19 @@ def main():
                 "flop_per_lr_pixel": 2 * total_macs,
             },
             "roofline": {
-                "kernel": "conv_igemm 3x3 (v_mfma_f32_16x16x4_f32), %d launches/pass" % len(dom),
+                "kernel": "%s 3x3 (v_mfma_f32_16x16x4_f32), %d launches/pass" % ("+".join(dom_kernels), len(dom)),
                 "bound": "mfma",
                 "achieved": round(achieved, 3),
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(len(dom)),
                 "algorithmic_flop_per_step": dom_flop,
+                "executed_flop_per_step": dom_exec,
+                "executed_tflops": round(executed, 3),
+                "mfma_pipe_util": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+                "note": "achieved counts the direct-form FLOPs of the conv; the Winograd F(2x2,3x3) kernel issues 16/36 "
+                        "of them (plus channel padding), so frac can exceed 1 while the MFMA pipe runs at mfma_pipe_util",
                 "kernel_ms_per_step": round(dom_ms, 4),
             },
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_kernel.items())},

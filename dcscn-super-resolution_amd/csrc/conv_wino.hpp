@@ -1,0 +1,283 @@
+// conv_wino: 3x3 SAME convolution as Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32.
+//
+//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A          (Lavin & Gray 2015; 16 multiplies per 2x2 outputs
+//                                                         instead of 36 = 2.25x fewer MFMAs than conv_igemm)
+//
+// 16 "frequency" GEMMs D_f[cout][tile] += U_f[cout][cin] * V_f[cin][tile], one per entry of the 4x4
+// transformed tile.  Mapping (differs from the usual "16 batched GEMMs" on purpose, to fit CDNA4):
+//
+// * workgroup = 4 waves = a 16x16 output-pixel tile = 8x8 Winograd tiles; wave w owns tile rows 2w, 2w+1
+//   (16 tiles = the 16 columns of the MFMA B operand) for ALL 16 frequencies and NT*16 output channels
+//   (NT <= 3: 16*NT accumulators of 4 VGPRs).  Lane (j = lane & 15, k = lane >> 4) is tile j, channel k of
+//   the 4-deep MFMA step.
+// * the input transform B^T d B is done ON THE FLY in registers: the raw halo tile is staged in LDS
+//   exactly as conv_igemm does (channel-major planes), each lane reads the 4x4 raw patch of its (tile,
+//   channel) and forms its 16 V_f values with 32 adds -- VALU work that co-issues with the MFMAs.  No
+//   transformed-input buffer exists anywhere.
+// * the output transform A^T m A is wave-local too: after the K loop a lane holds m_f for its tile and 4
+//   output channels for every f, so the 2x2 output pixels are 24 adds away; then bias/activator/store.
+// * filters are transformed once on the host in float64 (G g G^T), rounded to f32 and packed in the LDS
+//   image [f][kk][NS] per channel chunk.
+//
+// Numerics: F(2x2,3x3) has transform entries 0, +-1, +-1/2 only; measured error of one 196->166 layer is
+// 1.8x the direct form's (2e-4 vs 1.1e-4 on outputs of magnitude 275) and the end-to-end max-abs error of
+// the L12 network is unchanged at 1.6e-5 (dominated by the final add) -- inside the 1e-4 parity bar.
+#pragma once
+#include "conv_igemm.hpp"
+
+namespace dcscn {
+
+template <int NT, int KC>
+struct WinoGeom {
+    static constexpr int TH = 16, TW = 16;
+    static constexpr int HTH = TH + 2, HTW = TW + 2;
+    static constexpr int HP = HTH * HTW;
+    static constexpr int PS = conv_plane_stride(HP);
+    static constexpr int NS = conv_ns(NT);
+    static constexpr int KQ = KC / 4;
+    static constexpr int A_FLOATS = KC * PS;
+    static constexpr int B_FLOATS = 16 * KC * NS;
+    static constexpr int BUF = A_FLOATS + B_FLOATS;
+    static constexpr int A_ITEMS = HP * KQ;
+    static constexpr int A_LOADS = (A_ITEMS + 255) / 256;
+    static constexpr int B_VEC = B_FLOATS / 4;
+    static constexpr int B_LOADS = (B_VEC + 255) / 256;
+};
+
+// NT: channel tiles per group as packed (LDS image, bias indexing); NTV <= NT: tiles that are real in
+// this workgroup's group (the last group of a layer may be narrower) -- compile time, so the MFMA
+// stream stays branch free.
+template <int NT, int NTV, int KC>
+__device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
+    using G = WinoGeom<NT, KC>;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15;
+    const int lk = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int ntile = blockIdx.y;
+    const int y0 = ty * G::TH;
+    const int x0 = tx * G::TW;
+    const int H = a.H, W = a.W;
+    const float* in_img = a.in + (size_t)img * H * W * a.in_stride + a.in_off;
+
+    // ---- staging (same scheme as conv_igemm with a 16x16 pixel tile, single LDS buffer) ----
+    const float* a_src[G::A_LOADS];
+    int a_dst[G::A_LOADS];
+    int a_c4[G::A_LOADS];
+    bool a_item[G::A_LOADS], a_inb[G::A_LOADS];
+    static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
+        constexpr int i = decltype(i_)::value;
+        const int item = tid + 256 * i;
+        const int hp = item / G::KQ;
+        const int q = item - hp * G::KQ;
+        const int hy = hp / G::HTW;
+        const int hx = hp - hy * G::HTW;
+        const int gy = y0 + hy - 1;
+        const int gx = x0 + hx - 1;
+        a_item[i] = item < G::A_ITEMS;
+        a_inb[i] = a_item[i] && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        a_c4[i] = 4 * q;
+        a_dst[i] = 4 * q * G::PS + hp;
+        a_src[i] = in_img + ((size_t)(a_inb[i] ? gy : 0) * W + (a_inb[i] ? gx : 0)) * a.in_stride + 4 * q;
+    });
+    const float* b_src = a.wpack + (size_t)ntile * a.n_chunks * G::B_FLOATS + 4 * tid;
+
+    f32x4 areg[G::A_LOADS];
+    f32x4 breg[G::B_LOADS];
+
+    auto load_chunk = [&](int chunk) DCSCN_INL {
+        const int c0 = chunk * KC;
+        static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (a_inb[i] && c0 + a_c4[i] < a.cin_phys) v = *reinterpret_cast<const f32x4*>(a_src[i] + c0);
+            areg[i] = v;
+        });
+        const float* bs = b_src + (size_t)chunk * G::B_FLOATS;
+        static_for<0, G::B_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            if (i < G::B_LOADS - 1 || tid + 256 * i < G::B_VEC)
+                breg[i] = *reinterpret_cast<const f32x4*>(bs + 1024 * i);
+        });
+    };
+    auto store_chunk = [&](float* buf) DCSCN_INL {
+        static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            if (a_item[i]) {
+                float* d = buf + a_dst[i];
+                d[0] = areg[i].x;
+                d[G::PS] = areg[i].y;
+                d[2 * G::PS] = areg[i].z;
+                d[3 * G::PS] = areg[i].w;
+            }
+        });
+        float* bd = buf + G::A_FLOATS + 4 * tid;
+        static_for<0, G::B_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            if (i < G::B_LOADS - 1 || tid + 256 * i < G::B_VEC)
+                *reinterpret_cast<f32x4*>(bd + 1024 * i) = breg[i];
+        });
+    };
+
+    f32x4 acc[16][NTV];
+    static_for<0, 16>([&](auto f_) DCSCN_INL {
+        static_for<0, NTV>([&](auto n_) DCSCN_INL {
+            acc[decltype(f_)::value][decltype(n_)::value] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        });
+    });
+
+    // this lane's Winograd tile: rows 2w, 2w+1 of the 8x8 tile grid, 8 tiles per row
+    const int tr = 2 * wave + (lj >> 3);
+    const int tc = lj & 7;
+    const int a_lane = lk * G::PS + (2 * tr) * G::HTW + 2 * tc;   // raw 4x4 patch origin in the halo tile
+    const int b_lane = G::A_FLOATS + lk * G::NS + lj;
+
+    auto compute = [&](const float* buf) DCSCN_INL {
+        const float* As = buf + a_lane;
+        const float* Bs = buf + b_lane;
+        static_for<0, G::KQ>([&](auto ks_) DCSCN_INL {
+            constexpr int ks = decltype(ks_)::value;
+            // raw patch d[i][j], i = row, j = column (each row: 4 consecutive floats, 8-byte aligned)
+            float d[4][4];
+            static_for<0, 4>([&](auto i_) DCSCN_INL {
+                constexpr int i = decltype(i_)::value;
+                const float2 lo = *reinterpret_cast<const float2*>(As + (ks * 4) * G::PS + i * G::HTW);
+                const float2 hi = *reinterpret_cast<const float2*>(As + (ks * 4) * G::PS + i * G::HTW + 2);
+                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+            });
+            // V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+            float r[4][4], v[16];
+            static_for<0, 4>([&](auto j_) DCSCN_INL {
+                constexpr int j = decltype(j_)::value;
+                r[0][j] = d[0][j] - d[2][j];
+                r[1][j] = d[1][j] + d[2][j];
+                r[2][j] = d[2][j] - d[1][j];
+                r[3][j] = d[1][j] - d[3][j];
+            });
+            static_for<0, 4>([&](auto x_) DCSCN_INL {
+                constexpr int x = decltype(x_)::value;
+                v[4 * x + 0] = r[x][0] - r[x][2];
+                v[4 * x + 1] = r[x][1] + r[x][2];
+                v[4 * x + 2] = r[x][2] - r[x][1];
+                v[4 * x + 3] = r[x][1] - r[x][3];
+            });
+            static_for<0, 16>([&](auto f_) DCSCN_INL {
+                constexpr int f = decltype(f_)::value;
+                static_for<0, NTV>([&](auto n_) DCSCN_INL {
+                    constexpr int n = decltype(n_)::value;
+                    const float wv = Bs[(f * KC + ks * 4) * G::NS + n * 16];
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[f], acc[f][n], 0, 0, 0);
+                });
+            });
+        });
+    };
+
+    load_chunk(0);
+    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+        store_chunk(smem);
+        __syncthreads();
+        if (chunk + 1 < a.n_chunks) load_chunk(chunk + 1);
+        compute(smem);
+        __syncthreads();
+    }
+
+    // ---- output transform (wave-local) + epilogue ----
+    const int gy0 = y0 + 2 * tr;
+    const int gx0 = x0 + 2 * tc;
+    const int cbase = ntile * NT * 16;
+    const int act = a.act;
+    static_for<0, NTV>([&](auto n_) DCSCN_INL {
+        constexpr int n = decltype(n_)::value;
+        const int c = cbase + n * 16 + 4 * lk;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c);
+        f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (act == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(a.alpha + c);
+        const bool first = c < a.split;
+        float* optr = first ? a.out0.ptr : a.out1.ptr;
+        const int ostride = first ? a.out0.stride : a.out1.stride;
+        const int ooff = first ? a.out0.off : a.out1.off;
+        const int owidth = first ? a.out0.width : a.out1.width;
+        const int cc = first ? c : c - a.split;
+        int ch[4], ay[4], bx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ccr = cc + r;
+            if (a.ps == 1) {
+                ch[r] = ccr; ay[r] = 0; bx[r] = 0;
+            } else {
+                const int sub = ccr / a.ps_c;
+                ch[r] = ccr - sub * a.ps_c;
+                ay[r] = sub / a.ps;
+                bx[r] = sub - ay[r] * a.ps;
+            }
+        }
+        const size_t orow = (size_t)W * a.ps;
+        // t[a][nu] = sum_xi A^T[a][xi] m[xi][nu],  A^T = [1 1 1 0; 0 1 -1 -1]
+        f32x4 t0[4], t1[4];
+        static_for<0, 4>([&](auto nu_) DCSCN_INL {
+            constexpr int nu = decltype(nu_)::value;
+            t0[nu] = acc[0 + nu][n] + acc[4 + nu][n] + acc[8 + nu][n];
+            t1[nu] = acc[4 + nu][n] - acc[8 + nu][n] - acc[12 + nu][n];
+        });
+        f32x4 yv[2][2];
+        yv[0][0] = t0[0] + t0[1] + t0[2];
+        yv[0][1] = t0[1] - t0[2] - t0[3];
+        yv[1][0] = t1[0] + t1[1] + t1[2];
+        yv[1][1] = t1[1] - t1[2] - t1[3];
+        static_for<0, 2>([&](auto pa_) DCSCN_INL {
+            static_for<0, 2>([&](auto pb_) DCSCN_INL {
+                constexpr int pa = decltype(pa_)::value, pb = decltype(pb_)::value;
+                const int gy = gy0 + pa, gx = gx0 + pb;
+                if (gy < H && gx < W) {
+                    f32x4 v = yv[pa][pb] + bv;
+                    v.x = activate1(v.x, av.x, act);
+                    v.y = activate1(v.y, av.y, act);
+                    v.z = activate1(v.z, av.z, act);
+                    v.w = activate1(v.w, av.w, act);
+                    const size_t prow = ((size_t)img * H + gy) * a.ps;
+                    if (a.vec4) {
+                        if (cc < owidth) {
+                            const size_t pix = (prow + ay[0]) * orow + (size_t)gx * a.ps + bx[0];
+                            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + pix * a.res_stride + ch[0]);
+                            *reinterpret_cast<f32x4*>(optr + pix * ostride + ooff + ch[0]) = v;
+                        }
+                    } else {
+                        const float vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (cc + r < owidth) {
+                                const size_t pix = (prow + ay[r]) * orow + (size_t)gx * a.ps + bx[r];
+                                float out = vr[r];
+                                if (a.res) out += a.res[pix * a.res_stride + ch[r]];
+                                optr[pix * ostride + ooff + ch[r]] = out;
+                            }
+                        }
+                    }
+                }
+            });
+        });
+    });
+}
+
+template <int NT, int KC, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv_wino(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nt_valid = (blockIdx.y == gridDim.y - 1) ? a.nt_last : NT;   // block uniform
+    if (nt_valid == NT) conv_wino_body<NT, NT, KC>(a, smem);
+    else if constexpr (NT >= 2) {
+        if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC>(a, smem);
+        else if constexpr (NT >= 3) {
+            if (nt_valid == NT - 2) conv_wino_body<NT, NT - 2, KC>(a, smem);
+        }
+    }
+}
+
+}  // namespace dcscn

@@ -41,11 +41,13 @@ struct ConvArgs {
     // sum_t in(p + o_t)[c] * dww[t][c] instead of in(p)[c]
     const float* dww;         // [dwk*dwk][cin_phys], physical channel order, zero padded (or nullptr)
     int32_t dwk;              // depthwise kernel size: 0 (none), 1 or 3
+    int32_t nt_last;          // conv_wino: 16-channel tiles that are real in the last channel group
 };
 
 struct ConvShape {            // kernel variant picked by the plan
     int ks, mt, nt, kc;
     int dwk = 0;              // fused depthwise kernel size (ks == 1 only)
+    int wino = 0;             // 1: Winograd F(2x2,3x3) kernel (ks == 3, nt <= 3, 16x16 pixel tiles)
 };
 
 // Geometry helpers shared by the weight packer (host) and the kernels (device).
@@ -62,6 +64,11 @@ size_t conv_lds_bytes(const ConvShape& s);
 // One-time: raise the dynamic-LDS limit of every instantiated kernel. Returns hipSuccess or error.
 hipError_t conv_init_kernels();
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream);
+// Winograd F(2x2,3x3) variant of a 3x3 conv: `nt` channel tiles of 16 per group (1..3), `n_groups` groups,
+// args.nt_last = tiles in the last group, args.wpack in the [group][chunk][16 f][kk][NS] image.
+constexpr int kWinoKC = 4;
+constexpr int kWinoMaxNT = 3;
+hipError_t wino_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
 int conv_max_fused_dw_nt();
 

@@ -11,7 +11,7 @@
 // Layout: activations are NHWC float32; every tensor slice starts on a 4-channel boundary and is
 // padded to a multiple of 4 channels (padding lanes hold finite values and meet zero weights), so all
 // global traffic is 16-byte vectors.
-#include "conv_igemm.hpp"
+#include "conv_wino.hpp"
 
 namespace dcscn {
 
@@ -84,6 +84,26 @@ hipError_t conv_init_kernels() {
 }
 
 int conv_max_fused_dw_nt() { return kMaxDwNt; }
+
+// ---- Winograd variants -----------------------------------------------------------------------
+template <int NT>
+static hipError_t wino_launch_one(const ConvArgs& a, int n_groups, hipStream_t stream) {
+    using G = WinoGeom<NT, kWinoKC>;
+    const size_t lds = (size_t)G::BUF * sizeof(float);
+    const dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)n_groups);
+    hipLaunchKernelGGL((conv_wino<NT, kWinoKC, 2>), grid, dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t wino_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream) {
+    if (a.nt_last < 1 || a.nt_last > nt) return hipErrorInvalidValue;
+    switch (nt) {
+        case 1: return wino_launch_one<1>(a, n_groups, stream);
+        case 2: return wino_launch_one<2>(a, n_groups, stream);
+        case 3: return wino_launch_one<3>(a, n_groups, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
 
 template <int KS, int NT, int DWK = 0>
 static hipError_t conv_launch_one(const ConvArgs& a, int n_tiles, hipStream_t stream) {

@@ -89,6 +89,7 @@ class OpInfo(ctypes.Structure):
         ("n_tiles", ctypes.c_int32),
         ("macs_per_lr_pixel", ctypes.c_int64),
         ("bytes_per_lr_pixel", ctypes.c_int64),
+        ("executed_macs_per_lr_pixel", ctypes.c_int64),
     ]
 
 
@@ -258,8 +259,11 @@ class Engine:
         self._check(self._lib.dcscn_set_tensor(self._h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                                                shape, a.ndim))
 
-    def load_weights(self, tensors):
-        """Feed every variable the graph needs from ``{name: ndarray}`` and finalize."""
+    def load_weights(self, tensors, winograd=None):
+        """Feed every variable the graph needs from ``{name: ndarray}`` and finalize.
+        ``winograd=False`` keeps every 3x3 conv on the direct implicit-GEMM kernel (default: library choice)."""
+        if winograd is not None:
+            self.set_option("winograd", 1 if winograd else 0)
         for name, _ in self.tensor_specs():
             if name not in tensors:
                 raise EngineError(3, "variable '%s' is missing from the checkpoint" % name)

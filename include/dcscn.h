@@ -131,7 +131,7 @@ int dcscn_layer_info_get(dcscn_handle h, int index, dcscn_layer_info* out);
  * A launch covers one graph layer, or two when they are fused (A1 and B1 share one GEMM). */
 typedef struct dcscn_op_info {
     char    name[DCSCN_MAX_NAME];   /* e.g. "CNN2", "B1+A1", "CNN3/depthwise" */
-    char    kernel[32];             /* "conv_igemm", "conv_cin1", "conv_cout1", "depthwise" */
+    char    kernel[32];             /* "conv_igemm", "conv_wino", "conv_cin1", "conv_cout1", "depthwise" */
     int32_t kernel_size;
     int32_t in_channels;            /* logical */
     int32_t out_channels;           /* logical */
@@ -139,13 +139,17 @@ typedef struct dcscn_op_info {
     int32_t mt, nt, kc, n_tiles;    /* conv_igemm variant (0 for the other kernels) */
     int64_t macs_per_lr_pixel;      /* algorithmic multiply-accumulates per LR pixel */
     int64_t bytes_per_lr_pixel;     /* algorithmic activation bytes read + written per LR pixel */
+    int64_t executed_macs_per_lr_pixel; /* multiply-accumulates the kernel really issues: channel padding
+                                       included, 16/36 of the direct form for the Winograd kernel */
 } dcscn_op_info;
 int dcscn_num_ops(dcscn_handle h);
 int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
 
 /* Tunables: "sub_batch_pixels" (LR pixels processed per pass through the layer chain, default 4 Mi),
  * "workspace_budget_bytes" (caps the pass size so the activation workspace stays below it, default
- * 48 GiB), "profile" (1: time every launch with HIP events, read back with dcscn_get_profile). */
+ * 48 GiB), "profile" (1: time every launch with HIP events, read back with dcscn_get_profile),
+ * "winograd" (default 1; before dcscn_finalize only: 0 keeps every 3x3 conv on the direct
+ * implicit-GEMM kernel instead of the Winograd F(2x2,3x3) kernel). */
 int dcscn_set_option(dcscn_handle h, const char* key, int64_t value);
 
 /* Forward pass on host buffers: H2D, kernels, D2H, synchronous. */

@@ -13,19 +13,19 @@ pytestmark = pytest.mark.gpu
 MAX_ABS_TOL = 1e-4
 
 
-def _engine(cfg, weights):
+def _engine(cfg, weights, winograd=None):
     from dcscn_amd import engine
     eng = engine.Engine(cfg, device=0)
-    eng.load_weights(weights)
+    eng.load_weights(weights, winograd=winograd)
     return eng
 
 
-def _check(oracle, name, overrides, n, h, w, seed=0, sub_batch_pixels=None):
+def _check(oracle, name, overrides, n, h, w, seed=0, sub_batch_pixels=None, winograd=None):
     cfg = oracle.make_config(**overrides)
     weights = oracle.synthetic_weights(cfg, seed=seed)
     x, x2 = synthetic_batch(n, h, w, cfg["scale"], seed=seed + 1)
     ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
-    with _engine(cfg, weights) as eng:
+    with _engine(cfg, weights, winograd) as eng:
         if sub_batch_pixels:
             eng.set_option("sub_batch_pixels", sub_batch_pixels)
         y = eng.forward(x, x2)
@@ -37,18 +37,40 @@ def _check(oracle, name, overrides, n, h, w, seed=0, sub_batch_pixels=None):
     assert err <= MAX_ABS_TOL, "%s: max-abs error %.3g > %.1g" % (name, err, MAX_ABS_TOL)
 
 
+@pytest.mark.parametrize("winograd", [True, False])
 @pytest.mark.parametrize("name", sorted(CONFIGS))
-def test_config_48x48(oracle, name):
-    """Every BASELINE config (and every shipped-checkpoint topology) on 48x48 patches."""
+def test_config_48x48(oracle, name, winograd):
+    """Every BASELINE config (and every shipped-checkpoint topology) on 48x48 patches, with the 3x3
+    convs on the Winograd kernel (library default) and on the direct implicit-GEMM kernel."""
     n = 2 if "L12" in name or "L8" in name else 3
-    _check(oracle, name, CONFIGS[name], n, 48, 48)
+    _check(oracle, name, CONFIGS[name], n, 48, 48, winograd=winograd)
+
+
+@pytest.mark.parametrize("winograd", [True, False])
+def test_residual_branch_relative_error(oracle, winograd):
+    """The synthetic weights scale the last conv by 0.01, which would hide upstream errors behind the
+    bicubic term.  Here the last conv is NOT scaled and x2 = 0, so y is the bare network branch; its
+    error is bounded relative to its own magnitude (f32 accumulation over K <= 1764 terms)."""
+    cfg = oracle.make_config()
+    weights = oracle.synthetic_weights(cfg, seed=7)
+    weights["R-CNN1/conv_W"] = weights["R-CNN1/conv_W"] * 100.0
+    x, _ = synthetic_batch(2, 48, 48, 2, seed=8)
+    x2 = np.zeros((2, 96, 96, 1), np.float32)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with _engine(cfg, weights, winograd) as eng:
+        y = eng.forward(x, x2)
+    rel = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
+    print("winograd=%s residual-branch relative error %.3g (max|y| %.3g)" % (winograd, rel, np.max(np.abs(ref))))
+    assert rel <= 5e-6
 
 
 @pytest.mark.parametrize("hw", [(1, 1), (5, 7), (16, 16), (17, 33), (31, 9), (50, 20)])
 def test_ragged_sizes(oracle, hw):
-    """Image sizes that are not multiples of the 8x16 / 16x16 pixel tiles, down to a single pixel."""
+    """Image sizes that are not multiples of the pixel tiles (odd sizes also cut Winograd's 2x2 output
+    tiles), down to a single pixel; channel counts that are not multiples of 4 or 16."""
     _check(oracle, "L7_F32to8_x2", CONFIGS["L7_F32to8_x2"], 2, hw[0], hw[1])
     _check(oracle, "odd-channels", dict(layers=4, filters=37, min_filters=13, nin_filters=21, nin_filters2=10), 1, hw[0], hw[1])
+    _check(oracle, "wide-odd", dict(layers=3, filters=70, min_filters=45, nin_filters=40, nin_filters2=33), 1, hw[0], hw[1])
 
 
 def test_sub_batching_is_transparent(oracle):

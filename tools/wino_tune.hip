@@ -1,0 +1,189 @@
+// Correctness + timing harness for conv_wino against conv_igemm (same layer, same data).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino_tune.hip -o tools/wino_tune && ./tools/wino_tune
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../dcscn-super-resolution_amd/csrc/conv_wino.hpp"
+
+using namespace dcscn;
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                       \
+        }                                                                                  \
+    } while (0)
+
+static int N = 1024, H = 48, W = 48;
+
+struct Layer { const char* name; int cin, cout, in_stride, in_off, out_stride, out_off; };
+
+static std::vector<float> rand_vec(size_t n, unsigned seed, float scale) {
+    std::vector<float> h(n);
+    unsigned s = seed;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = (((s >> 8) & 0xffff) / 65536.0f - 0.5f) * scale; }
+    return h;
+}
+
+// direct pack: [chunk][tap][kk][NS]
+static std::vector<float> pack_direct(const std::vector<float>& w, int cin, int cout, int cin_phys, int kc, int nt, int* n_chunks) {
+    const int ns = conv_ns(nt);
+    *n_chunks = (cin_phys + kc - 1) / kc;
+    std::vector<float> p((size_t)*n_chunks * 9 * kc * ns, 0.0f);
+    for (int t = 0; t < 9; ++t)
+        for (int c = 0; c < cin; ++c)
+            for (int o = 0; o < cout; ++o)
+                p[((size_t)(c / kc) * 9 + t) * kc * ns + (size_t)(c % kc) * ns + o] = w[((size_t)t * cin + c) * cout + o];
+    return p;
+}
+
+// winograd pack: [ntile][chunk][f][kk][NS], U = G g G^T in double
+static std::vector<float> pack_wino(const std::vector<float>& w, int cin, int cout, int cin_phys, int kc, int nt, int* n_chunks, int* n_tiles, int* nt_last) {
+    const int ns = conv_ns(nt);
+    const int tiles16 = (cout + 15) / 16;
+    *n_tiles = (tiles16 + nt - 1) / nt;
+    *nt_last = tiles16 - (*n_tiles - 1) * nt;
+    *n_chunks = (cin_phys + kc - 1) / kc;
+    const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::vector<float> p((size_t)*n_tiles * *n_chunks * 16 * kc * ns, 0.0f);
+    for (int c = 0; c < cin; ++c)
+        for (int o = 0; o < cout; ++o) {
+            double g[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) g[i][j] = w[((size_t)(i * 3 + j) * cin + c) * cout + o];
+            const int tile = o / (nt * 16), jn = o % (nt * 16);
+            for (int xi = 0; xi < 4; ++xi)
+                for (int nu = 0; nu < 4; ++nu) {
+                    double u = 0;
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) u += G[xi][i] * g[i][j] * G[nu][j];
+                    const int f = xi * 4 + nu;
+                    p[(((size_t)tile * *n_chunks + c / kc) * 16 + f) * kc * ns + (size_t)(c % kc) * ns + jn] = (float)u;
+                }
+        }
+    return p;
+}
+
+template <typename K>
+static float time_kernel(K kern, dim3 grid, size_t lds, const ConvArgs& a, int reps = 5) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a);
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    CK(hipGetLastError());
+    return best;
+}
+
+static float *g_in, *g_ref, *g_out, *g_w, *g_bias;
+
+template <int MT, int NTD, int NTW, int KCW, int WPSW>
+void run(const Layer& L) {
+    const int cin_phys = (L.cin + 3) & ~3;
+    std::vector<float> w = rand_vec((size_t)9 * L.cin * L.cout, 777, 0.2f);
+    ConvArgs a{};
+    a.in = g_in; a.in_stride = L.in_stride; a.in_off = L.in_off; a.cin_phys = cin_phys;
+    a.bias = g_bias; a.alpha = g_bias; a.act = ACT_ALPHA;
+    a.N = N; a.H = H; a.W = W;
+    a.split = 1 << 30; a.ps = 1; a.ps_c = 1; a.vec4 = 1; a.res = nullptr; a.res_stride = 1;
+    const double flop = 2.0 * 9 * L.cin * (double)L.cout * N * H * W;
+
+    // reference: direct kernel
+    {
+        using Gd = ConvGeom<3, MT, NTD, 4>;
+        int nch;
+        std::vector<float> p = pack_direct(w, L.cin, L.cout, cin_phys, 4, NTD, &nch);
+        CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+        a.wpack = g_w; a.n_chunks = nch;
+        a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gd::TH - 1) / Gd::TH;
+        a.out0 = OutDesc{g_ref, L.out_stride, L.out_off, (L.cout + 3) & ~3};
+        a.out1 = a.out0;
+        auto kern = conv_igemm<3, MT, NTD, 4, false, 3>;
+        const size_t lds = (size_t)Gd::BUF * sizeof(float);
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const float ms = time_kernel(kern, dim3(N * a.tiles_y * a.tiles_x, 1), lds, a);
+        printf("%-8s %4d->%-4d direct MT%d NT%-2d            %8.3f ms  %7.2f TFLOP/s\n", L.name, L.cin, L.cout, MT, NTD, ms, flop / (ms * 1e-3) / 1e12);
+    }
+    // winograd
+    {
+        using Gw = WinoGeom<NTW, KCW>;
+        int nch, ntiles, ntlast;
+        std::vector<float> p = pack_wino(w, L.cin, L.cout, cin_phys, KCW, NTW, &nch, &ntiles, &ntlast);
+        CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+        a.wpack = g_w; a.n_chunks = nch; a.nt_last = ntlast;
+        a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
+        a.out0 = OutDesc{g_out, L.out_stride, L.out_off, (L.cout + 3) & ~3};
+        a.out1 = a.out0;
+        auto kern = conv_wino<NTW, KCW, WPSW>;
+        const size_t lds = (size_t)Gw::BUF * sizeof(float);
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int occ = 0;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds));
+        CK(hipMemset(g_out, 0, (size_t)N * H * W * L.out_stride * sizeof(float)));
+        const float ms = time_kernel(kern, dim3(N * a.tiles_y * a.tiles_x, ntiles), lds, a);
+        // compare on a sample of images
+        const size_t cnt = (size_t)8 * H * W * L.out_stride;
+        std::vector<float> r(cnt), o(cnt);
+        CK(hipMemcpy(r.data(), g_ref, cnt * sizeof(float), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(o.data(), g_out, cnt * sizeof(float), hipMemcpyDeviceToHost));
+        double maxd = 0, maxv = 0;
+        for (size_t px = 0; px < (size_t)8 * H * W; ++px)
+            for (int c = 0; c < L.cout; ++c) {
+                const size_t i = px * L.out_stride + L.out_off + c;
+                maxd = std::fmax(maxd, std::fabs((double)r[i] - o[i]));
+                maxv = std::fmax(maxv, std::fabs((double)r[i]));
+            }
+        printf("%-8s %4d->%-4d wino   NT%d KC%d WPS%d tiles%d lds %5.1f KB occ %d  %8.3f ms  %7.2f TFLOP/s(alg)  max|diff| %.3g (max|ref| %.3g)\n",
+               L.name, L.cin, L.cout, NTW, KCW, WPSW, ntiles, lds / 1024.0, occ, ms, flop / (ms * 1e-3) / 1e12, maxd, maxv);
+    }
+    fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) N = atoi(argv[1]);
+    const size_t act = (size_t)N * H * W * 1316;
+    CK(hipMalloc(&g_in, act * sizeof(float)));
+    CK(hipMalloc(&g_ref, act * sizeof(float)));
+    CK(hipMalloc(&g_out, act * sizeof(float)));
+    CK(hipMalloc(&g_w, (size_t)(32u << 20) * sizeof(float)));
+    CK(hipMalloc(&g_bias, 4096 * sizeof(float)));
+    {
+        std::vector<float> h = rand_vec(16u << 20, 4242, 100.0f);
+        for (size_t off = 0; off < act; off += h.size())
+            CK(hipMemcpy(g_in + off, h.data(), std::min(h.size(), act - off) * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<float> b = rand_vec(4096, 99, 0.5f);
+        for (auto& v : b) v = std::fabs(v) * 0.5f;
+        CK(hipMemcpy(g_bias, b.data(), 4096 * sizeof(float), hipMemcpyHostToDevice));
+    }
+    CK(hipMemset(g_ref, 0, act * sizeof(float)));
+    const Layer cnn2{"CNN2", 196, 166, 1316, 0, 1316, 196};
+    const Layer cnn5{"CNN5", 133, 120, 1316, 512, 1316, 648};
+    const Layer cnn8{"CNN8", 97, 86, 1316, 984, 1316, 1084};
+    const Layer cnn12{"CNN12", 57, 48, 1316, 1248, 1316, 1268};
+    const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
+    run<2, 11, 3, 4, 2>(cnn2);
+    run<2, 11, 2, 4, 2>(cnn2);
+    run<2, 11, 2, 8, 2>(cnn2);
+    run<2, 8, 3, 4, 2>(cnn5);
+    run<3, 6, 3, 4, 2>(cnn8);
+    run<4, 3, 3, 4, 2>(cnn12);
+    run<2, 12, 3, 4, 2>(upps);
+    return 0;
+}
