@@ -577,7 +577,9 @@ int finalize_op(dcscn_ctx* h, Op& op) {
         op.n_chunks = (op.cin_phys + kWinoKC - 1) / kWinoKC;
         const int ns = conv_ns(nt), kc = kWinoKC;
         const size_t chunk_floats = (size_t)16 * kc * ns;
-        std::vector<float> pack((size_t)op.n_tiles * op.n_chunks * chunk_floats, 0.0f);
+        // + one staging sweep of slack: the kernel loads the last partial sweep of a chunk with every
+        // thread (only the LDS store is predicated), which may run past the final chunk by < 2048 floats
+        std::vector<float> pack((size_t)op.n_tiles * op.n_chunks * chunk_floats + 2048, 0.0f);
         std::vector<float> bias(op.ctot, 0.0f), alpha(op.ctot, 0.0f);
         const ColSeg& sg = op.segs[0];
         const TensorSpec& tw = h->tensors[sg.w];            // [3, 3, cin, cout]

@@ -27,9 +27,10 @@
 
 namespace dcscn {
 
-template <int NT, int KC>
+template <int NT, int KC, int WAVES = 4>
 struct WinoGeom {
-    static constexpr int TH = 16, TW = 16;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int TH = 4 * WAVES, TW = 16;
     static constexpr int HTH = TH + 2, HTW = TW + 2;
     static constexpr int HP = HTH * HTW;
     static constexpr int PS = conv_plane_stride(HP);
@@ -39,17 +40,18 @@ struct WinoGeom {
     static constexpr int B_FLOATS = 16 * KC * NS;
     static constexpr int BUF = A_FLOATS + B_FLOATS;
     static constexpr int A_ITEMS = HP * KQ;
-    static constexpr int A_LOADS = (A_ITEMS + 255) / 256;
+    static constexpr int A_LOADS = (A_ITEMS + THREADS - 1) / THREADS;
     static constexpr int B_VEC = B_FLOATS / 4;
-    static constexpr int B_LOADS = (B_VEC + 255) / 256;
+    static constexpr int B_LOADS = (B_VEC + THREADS - 1) / THREADS;
 };
 
 // NT: channel tiles per group as packed (LDS image, bias indexing); NTV <= NT: tiles that are real in
 // this workgroup's group (the last group of a layer may be narrower) -- compile time, so the MFMA
 // stream stays branch free.
-template <int NT, int NTV, int KC>
+template <int NT, int NTV, int KC, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false>
 __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
-    using G = WinoGeom<NT, KC>;
+    using G = WinoGeom<NT, KC, WAVES>;
+    constexpr int THREADS = G::THREADS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -75,7 +77,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     bool a_item[G::A_LOADS], a_inb[G::A_LOADS];
     static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
         constexpr int i = decltype(i_)::value;
-        const int item = tid + 256 * i;
+        const int item = tid + THREADS * i;
         const int hp = item / G::KQ;
         const int q = item - hp * G::KQ;
         const int hy = hp / G::HTW;
@@ -86,44 +88,49 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
         a_inb[i] = a_item[i] && gy >= 0 && gy < H && gx >= 0 && gx < W;
         a_c4[i] = 4 * q;
         a_dst[i] = 4 * q * G::PS + hp;
-        a_src[i] = in_img + ((size_t)(a_inb[i] ? gy : 0) * W + (a_inb[i] ? gx : 0)) * a.in_stride + 4 * q;
+        // always a valid address (pixel (0,0) for halo positions outside the image): loads are issued
+        // unconditionally and masked when written to LDS, so no branch sits between a load and its use
+        a_src[i] = in_img + ((size_t)(a_inb[i] ? gy : 0) * W + (a_inb[i] ? gx : 0)) * a.in_stride;
     });
     const float* b_src = a.wpack + (size_t)ntile * a.n_chunks * G::B_FLOATS + 4 * tid;
+    const int c_last = a.cin_phys - 4;
 
     f32x4 areg[G::A_LOADS];
     f32x4 breg[G::B_LOADS];
 
+    // NOTE: the filter buffer is over-allocated by one staging sweep, so the last (partial) sweep of a
+    // chunk may be loaded by every thread; only its LDS store is predicated.
     auto load_chunk = [&](int chunk) DCSCN_INL {
         const int c0 = chunk * KC;
         static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (a_inb[i] && c0 + a_c4[i] < a.cin_phys) v = *reinterpret_cast<const f32x4*>(a_src[i] + c0);
-            areg[i] = v;
+            const int c = c0 + a_c4[i];
+            areg[i] = *reinterpret_cast<const f32x4*>(a_src[i] + (c < c_last ? c : c_last));
         });
         const float* bs = b_src + (size_t)chunk * G::B_FLOATS;
         static_for<0, G::B_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
-            if (i < G::B_LOADS - 1 || tid + 256 * i < G::B_VEC)
-                breg[i] = *reinterpret_cast<const f32x4*>(bs + 1024 * i);
+            breg[i] = *reinterpret_cast<const f32x4*>(bs + 4 * THREADS * i);
         });
     };
-    auto store_chunk = [&](float* buf) DCSCN_INL {
+    auto store_chunk = [&](float* buf, int chunk) DCSCN_INL {
+        const int c0 = chunk * KC;
         static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
             if (a_item[i]) {
+                const bool keep = a_inb[i] && c0 + a_c4[i] < a.cin_phys;
                 float* d = buf + a_dst[i];
-                d[0] = areg[i].x;
-                d[G::PS] = areg[i].y;
-                d[2 * G::PS] = areg[i].z;
-                d[3 * G::PS] = areg[i].w;
+                d[0] = keep ? areg[i].x : 0.0f;
+                d[G::PS] = keep ? areg[i].y : 0.0f;
+                d[2 * G::PS] = keep ? areg[i].z : 0.0f;
+                d[3 * G::PS] = keep ? areg[i].w : 0.0f;
             }
         });
         float* bd = buf + G::A_FLOATS + 4 * tid;
         static_for<0, G::B_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
-            if (i < G::B_LOADS - 1 || tid + 256 * i < G::B_VEC)
-                *reinterpret_cast<f32x4*>(bd + 1024 * i) = breg[i];
+            if (i < G::B_LOADS - 1 || tid + THREADS * i < G::B_VEC)
+                *reinterpret_cast<f32x4*>(bd + 4 * THREADS * i) = breg[i];
         });
     };
 
@@ -143,14 +150,16 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     auto compute = [&](const float* buf) DCSCN_INL {
         const float* As = buf + a_lane;
         const float* Bs = buf + b_lane;
-        static_for<0, G::KQ>([&](auto ks_) DCSCN_INL {
-            constexpr int ks = decltype(ks_)::value;
+        // one 4-channel MFMA step per iteration; NOT unrolled across steps so that only one step's raw
+        // patch / transformed operands are live next to the 16*NT accumulators
+#pragma unroll 1
+        for (int ks = 0; ks < G::KQ; ++ks, As += 4 * G::PS, Bs += 4 * G::NS) {
             // raw patch d[i][j], i = row, j = column (each row: 4 consecutive floats, 8-byte aligned)
             float d[4][4];
             static_for<0, 4>([&](auto i_) DCSCN_INL {
                 constexpr int i = decltype(i_)::value;
-                const float2 lo = *reinterpret_cast<const float2*>(As + (ks * 4) * G::PS + i * G::HTW);
-                const float2 hi = *reinterpret_cast<const float2*>(As + (ks * 4) * G::PS + i * G::HTW + 2);
+                const float2 lo = *reinterpret_cast<const float2*>(As + i * G::HTW);
+                const float2 hi = *reinterpret_cast<const float2*>(As + i * G::HTW + 2);
                 d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
             });
             // V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
@@ -173,20 +182,124 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
                 constexpr int f = decltype(f_)::value;
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
                     constexpr int n = decltype(n_)::value;
-                    const float wv = Bs[(f * KC + ks * 4) * G::NS + n * 16];
+                    const float wv = Bs[(f * KC) * G::NS + n * 16];
                     acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[f], acc[f][n], 0, 0, 0);
                 });
             });
+        }
+    };
+
+    // ---- filters by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no registers) ----
+    auto dma_filters = [&](int chunk, float* buf) DCSCN_INL {
+        constexpr int PIECES = G::B_FLOATS / 256;
+        static_assert(G::B_FLOATS % 256 == 0, "filter block must be whole 1 KB DMA pieces");
+        const float* src = a.wpack + ((size_t)ntile * a.n_chunks + chunk) * G::B_FLOATS + 4 * lane;
+        float* dst = buf + G::A_FLOATS;
+        static_for<0, (PIECES + WAVES - 1) / WAVES>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            const int piece = wave + WAVES * i;            // wave uniform
+            if (PIECES % WAVES == 0 || piece < PIECES)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + 256 * piece),
+                    (__attribute__((address_space(3))) void*)(dst + 256 * piece), 16, 0, 0);
+        });
+    };
+    auto load_input = [&](int chunk) DCSCN_INL {
+        const int c0 = chunk * KC;
+        static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            const int c = c0 + a_c4[i];
+            areg[i] = *reinterpret_cast<const f32x4*>(a_src[i] + (c < c_last ? c : c_last));
+        });
+    };
+    auto store_input = [&](float* buf, int chunk) DCSCN_INL {
+        const int c0 = chunk * KC;
+        static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            if (a_item[i]) {
+                const bool keep = a_inb[i] && c0 + a_c4[i] < a.cin_phys;
+                float* d = buf + a_dst[i];
+                d[0] = keep ? areg[i].x : 0.0f;
+                d[G::PS] = keep ? areg[i].y : 0.0f;
+                d[2 * G::PS] = keep ? areg[i].z : 0.0f;
+                d[3 * G::PS] = keep ? areg[i].w : 0.0f;
+            }
         });
     };
 
-    load_chunk(0);
-    for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
-        store_chunk(smem);
+    if constexpr (DMA) {
+        // two LDS buffers; filters of chunk c+1 stream in by DMA and the input tile of chunk c+1 sits in
+        // registers while chunk c is multiplied; ONE barrier per chunk (hipcc drains vmcnt(0) -- i.e. the
+        // DMA -- in front of __syncthreads by itself)
+        dma_filters(0, smem);
+        load_input(0);
+        store_input(smem, 0);
         __syncthreads();
-        if (chunk + 1 < a.n_chunks) load_chunk(chunk + 1);
-        compute(smem);
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            float* cur = smem + (chunk & 1) * G::BUF;
+            float* nxt = smem + ((chunk + 1) & 1) * G::BUF;
+            const bool more = chunk + 1 < a.n_chunks;
+            if (more) {
+                dma_filters(chunk + 1, nxt);
+                load_input(chunk + 1);
+            }
+            compute(cur);
+            if (more) store_input(nxt, chunk + 1);
+            __syncthreads();
+        }
+    } else if constexpr (ABLATE == 2) {
+        // tuner only: pure compute phase (no staging, no barriers) -- the ceiling of the MFMA loop
+        load_chunk(0);
+        store_chunk(smem, 0);
         __syncthreads();
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) compute(smem);
+    } else if constexpr (ABLATE == 3) {
+        // tuner only: barriers kept, no staging
+        load_chunk(0);
+        store_chunk(smem, 0);
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            __syncthreads();
+            compute(smem);
+            __syncthreads();
+        }
+    } else if constexpr (ABLATE == 4) {
+        // tuner only: LDS stores kept, no barriers, no global loads (racy)
+        load_chunk(0);
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            store_chunk(smem, 0);
+            compute(smem);
+        }
+    } else if constexpr (ABLATE == 1) {
+        // tuner only: staging and barriers kept, global loads issued once
+        load_chunk(0);
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            store_chunk(smem, 0);
+            __syncthreads();
+            compute(smem);
+            __syncthreads();
+        }
+    } else if constexpr (DB) {
+        load_chunk(0);
+        store_chunk(smem, 0);
+        __syncthreads();
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            float* cur = smem + (chunk & 1) * G::BUF;
+            float* nxt = smem + ((chunk + 1) & 1) * G::BUF;
+            const bool more = chunk + 1 < a.n_chunks;
+            if (more) load_chunk(chunk + 1);
+            compute(cur);
+            if (more) store_chunk(nxt, chunk + 1);
+            __syncthreads();
+        }
+    } else {
+        load_chunk(0);
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            store_chunk(smem, chunk);
+            __syncthreads();
+            if (chunk + 1 < a.n_chunks) load_chunk(chunk + 1);
+            compute(smem);
+            __syncthreads();
+        }
     }
 
     // ---- output transform (wave-local) + epilogue ----
@@ -267,15 +380,17 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     });
 }
 
-template <int NT, int KC, int WPS>
-__global__ __launch_bounds__(256, WPS) void conv_wino(const ConvArgs a) {
+// WAVES waves per workgroup = a (4*WAVES) x 16 output-pixel tile; launch_bounds' second argument is
+// waves per SIMD: WPS workgroups of 4 waves, or WPS/2 workgroups of 8.
+template <int NT, int KC, int WPS, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false>
+__global__ __launch_bounds__(64 * WAVES, WPS) void conv_wino(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nt_valid = (blockIdx.y == gridDim.y - 1) ? a.nt_last : NT;   // block uniform
-    if (nt_valid == NT) conv_wino_body<NT, NT, KC>(a, smem);
+    if (nt_valid == NT) conv_wino_body<NT, NT, KC, DB, ABLATE, WAVES, DMA>(a, smem);
     else if constexpr (NT >= 2) {
-        if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC>(a, smem);
+        if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC, DB, ABLATE, WAVES, DMA>(a, smem);
         else if constexpr (NT >= 3) {
-            if (nt_valid == NT - 2) conv_wino_body<NT, NT - 2, KC>(a, smem);
+            if (nt_valid == NT - 2) conv_wino_body<NT, NT - 2, KC, DB, ABLATE, WAVES, DMA>(a, smem);
         }
     }
 }

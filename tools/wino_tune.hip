@@ -22,6 +22,7 @@ using namespace dcscn;
     } while (0)
 
 static int N = 1024, H = 48, W = 48;
+static int g_lds_mul = 1;
 
 struct Layer { const char* name; int cin, cout, in_stride, in_off, out_stride, out_off; };
 
@@ -72,16 +73,16 @@ static std::vector<float> pack_wino(const std::vector<float>& w, int cin, int co
 }
 
 template <typename K>
-static float time_kernel(K kern, dim3 grid, size_t lds, const ConvArgs& a, int reps = 5) {
+static float time_kernel(K kern, dim3 grid, size_t lds, const ConvArgs& a, int reps = 5, int threads = 256) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, grid, dim3(threads), lds, 0, a);
     CK(hipDeviceSynchronize());
     float best = 1e30f;
     for (int i = 0; i < reps; ++i) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a);
+        hipLaunchKernelGGL(kern, grid, dim3(threads), lds, 0, a);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -94,7 +95,7 @@ static float time_kernel(K kern, dim3 grid, size_t lds, const ConvArgs& a, int r
 
 static float *g_in, *g_ref, *g_out, *g_w, *g_bias;
 
-template <int MT, int NTD, int NTW, int KCW, int WPSW>
+template <int MT, int NTD, int NTW, int KCW, int WPSW, bool DBW = false, int ABL = 0, int WAVES = 4, bool DMA = false>
 void run(const Layer& L) {
     const int cin_phys = (L.cin + 3) & ~3;
     std::vector<float> w = rand_vec((size_t)9 * L.cin * L.cout, 777, 0.2f);
@@ -123,21 +124,21 @@ void run(const Layer& L) {
     }
     // winograd
     {
-        using Gw = WinoGeom<NTW, KCW>;
+        using Gw = WinoGeom<NTW, KCW, WAVES>;
         int nch, ntiles, ntlast;
         std::vector<float> p = pack_wino(w, L.cin, L.cout, cin_phys, KCW, NTW, &nch, &ntiles, &ntlast);
         CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
         a.wpack = g_w; a.n_chunks = nch; a.nt_last = ntlast;
-        a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 15) / 16;
+        a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gw::TH - 1) / Gw::TH;
         a.out0 = OutDesc{g_out, L.out_stride, L.out_off, (L.cout + 3) & ~3};
         a.out1 = a.out0;
-        auto kern = conv_wino<NTW, KCW, WPSW>;
-        const size_t lds = (size_t)Gw::BUF * sizeof(float);
+        auto kern = conv_wino<NTW, KCW, WPSW, DBW, ABL, WAVES, DMA>;
+        const size_t lds = ((DBW || DMA) ? 2 : 1) * (size_t)Gw::BUF * sizeof(float) * (size_t)g_lds_mul;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int occ = 0;
-        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds));
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WAVES, lds));
         CK(hipMemset(g_out, 0, (size_t)N * H * W * L.out_stride * sizeof(float)));
-        const float ms = time_kernel(kern, dim3(N * a.tiles_y * a.tiles_x, ntiles), lds, a);
+        const float ms = time_kernel(kern, dim3(N * a.tiles_y * a.tiles_x, ntiles), lds, a, 5, 64 * WAVES);
         // compare on a sample of images
         const size_t cnt = (size_t)8 * H * W * L.out_stride;
         std::vector<float> r(cnt), o(cnt);
@@ -150,14 +151,15 @@ void run(const Layer& L) {
                 maxd = std::fmax(maxd, std::fabs((double)r[i] - o[i]));
                 maxv = std::fmax(maxv, std::fabs((double)r[i]));
             }
-        printf("%-8s %4d->%-4d wino   NT%d KC%d WPS%d tiles%d lds %5.1f KB occ %d  %8.3f ms  %7.2f TFLOP/s(alg)  max|diff| %.3g (max|ref| %.3g)\n",
-               L.name, L.cin, L.cout, NTW, KCW, WPSW, ntiles, lds / 1024.0, occ, ms, flop / (ms * 1e-3) / 1e12, maxd, maxv);
+        printf("%-8s %4d->%-4d wino W%d DB%d DMA%d ABL%d NT%d KC%d WPS%d tiles%d lds %5.1f KB occ %d  %8.3f ms  %7.2f TFLOP/s(alg)  max|diff| %.3g (max|ref| %.3g)\n",
+               L.name, L.cin, L.cout, WAVES, (int)DBW, (int)DMA, ABL, NTW, KCW, WPSW, ntiles, lds / 1024.0, occ, ms, flop / (ms * 1e-3) / 1e12, maxd, maxv);
     }
     fflush(stdout);
 }
 
 int main(int argc, char** argv) {
     if (argc > 1) N = atoi(argv[1]);
+    if (getenv("WINO_LDS_MUL")) g_lds_mul = atoi(getenv("WINO_LDS_MUL"));
     const size_t act = (size_t)N * H * W * 1316;
     CK(hipMalloc(&g_in, act * sizeof(float)));
     CK(hipMalloc(&g_ref, act * sizeof(float)));
@@ -179,11 +181,11 @@ int main(int argc, char** argv) {
     const Layer cnn12{"CNN12", 57, 48, 1316, 1248, 1316, 1268};
     const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
     run<2, 11, 3, 4, 2>(cnn2);
-    run<2, 11, 2, 4, 2>(cnn2);
-    run<2, 11, 2, 8, 2>(cnn2);
-    run<2, 8, 3, 4, 2>(cnn5);
-    run<3, 6, 3, 4, 2>(cnn8);
+    run<2, 11, 3, 4, 2, true>(cnn2);
+    run<2, 11, 3, 4, 2, false, 0, 4, true>(cnn2);
+    run<2, 11, 3, 8, 2, false, 0, 4, true>(cnn2);
     run<4, 3, 3, 4, 2>(cnn12);
-    run<2, 12, 3, 4, 2>(upps);
+    run<4, 3, 3, 4, 2, true>(cnn12);
+    run<4, 3, 3, 8, 2, false, 0, 4, true>(cnn12);
     return 0;
 }
