@@ -88,10 +88,17 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X; there is no CPU fallback for the HIP path")
-    torch.cuda.set_device(local_rank)
+    # test hook: DCSCN_BENCH_SHARE_GPU=1 lets several ranks share one device over gloo, to exercise the
+    # multi-rank code path on a single-GPU box; real runs use one GPU per rank over RCCL
+    share_gpu = os.environ.get("DCSCN_BENCH_SHARE_GPU") == "1"
+    device_index = local_rank % torch.cuda.device_count() if share_gpu else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
 
     from dcscn_amd import engine
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -99,7 +106,7 @@ def main():
 
     cfg = O.make_config(**MODEL_FLAGS)
     weights = O.synthetic_weights(cfg, seed=0)
-    eng = engine.Engine(cfg, device=local_rank)
+    eng = engine.Engine(cfg, device=device_index)
     eng.load_weights(weights, winograd=False if args.no_winograd else None)
     if args.sub_batch_pixels:
         eng.set_option("sub_batch_pixels", args.sub_batch_pixels)
@@ -133,7 +140,7 @@ def main():
     per_op_ms = eng.profile()         # averaged over the timed steps
     eng.set_option("profile", 0)
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if share_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not bool(torch.isfinite(y).all().item()):
@@ -192,7 +199,7 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": pmc_traffic(len(dom)),
+                "traffic": pmc_traffic(len(dom)) if n == PATCHES_PER_GPU else None,
                 "algorithmic_flop_per_step": dom_flop,
                 "executed_flop_per_step": dom_exec,
                 "executed_tflops": round(executed, 3),

@@ -48,7 +48,7 @@ struct WinoGeom {
 // NT: channel tiles per group as packed (LDS image, bias indexing); NTV <= NT: tiles that are real in
 // this workgroup's group (the last group of a layer may be narrower) -- compile time, so the MFMA
 // stream stays branch free.
-template <int NT, int NTV, int KC, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false>
+template <int NT, int NTV, int KC, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false, int PRIO = 0>
 __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     using G = WinoGeom<NT, KC, WAVES>;
     constexpr int THREADS = G::THREADS;
@@ -150,6 +150,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     auto compute = [&](const float* buf) DCSCN_INL {
         const float* As = buf + a_lane;
         const float* Bs = buf + b_lane;
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(PRIO);
         // one 4-channel MFMA step per iteration; NOT unrolled across steps so that only one step's raw
         // patch / transformed operands are live next to the 16*NT accumulators
 #pragma unroll 1
@@ -187,6 +188,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
                 });
             });
         }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- filters by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no registers) ----
@@ -382,15 +384,15 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
 
 // WAVES waves per workgroup = a (4*WAVES) x 16 output-pixel tile; launch_bounds' second argument is
 // waves per SIMD: WPS workgroups of 4 waves, or WPS/2 workgroups of 8.
-template <int NT, int KC, int WPS, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false>
+template <int NT, int KC, int WPS, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false, int PRIO = 0>
 __global__ __launch_bounds__(64 * WAVES, WPS) void conv_wino(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nt_valid = (blockIdx.y == gridDim.y - 1) ? a.nt_last : NT;   // block uniform
-    if (nt_valid == NT) conv_wino_body<NT, NT, KC, DB, ABLATE, WAVES, DMA>(a, smem);
+    if (nt_valid == NT) conv_wino_body<NT, NT, KC, DB, ABLATE, WAVES, DMA, PRIO>(a, smem);
     else if constexpr (NT >= 2) {
-        if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC, DB, ABLATE, WAVES, DMA>(a, smem);
+        if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC, DB, ABLATE, WAVES, DMA, PRIO>(a, smem);
         else if constexpr (NT >= 3) {
-            if (nt_valid == NT - 2) conv_wino_body<NT, NT - 2, KC, DB, ABLATE, WAVES, DMA>(a, smem);
+            if (nt_valid == NT - 2) conv_wino_body<NT, NT - 2, KC, DB, ABLATE, WAVES, DMA, PRIO>(a, smem);
         }
     }
 }

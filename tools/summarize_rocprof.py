@@ -51,7 +51,7 @@ def main(src, dst, tag):
         out = {}
         for k in pmc:
             n = max(calls[k], 1)
-            out[k] = {"dispatches": calls[k], "avg_duration_ns_profiled": dur[k] / n}
+            out[k] = {"dispatches": calls[k], "forwards": 4, "avg_duration_ns_profiled": dur[k] / n}
             out[k].update({c: v / n for c, v in pmc[k].items()})
         with open(os.path.join(dst, "%s_pmc_per_dispatch.json" % tag), "w") as f:
             json.dump({"note": "per-dispatch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported (uncalibrated, "
