@@ -48,7 +48,7 @@ struct WinoGeom {
 // NT: channel tiles per group as packed (LDS image, bias indexing); NTV <= NT: tiles that are real in
 // this workgroup's group (the last group of a layer may be narrower) -- compile time, so the MFMA
 // stream stays branch free.
-template <int NT, int NTV, int KC, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false, int PRIO = 0>
+template <int NT, int NTV, int KC, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false, int PRIO = 0, int PF = 0, bool VPIPE = false>
 __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     using G = WinoGeom<NT, KC, WAVES>;
     constexpr int THREADS = G::THREADS;
@@ -147,38 +147,37 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     const int a_lane = lk * G::PS + (2 * tr) * G::HTW + 2 * tc;   // raw 4x4 patch origin in the halo tile
     const int b_lane = G::A_FLOATS + lk * G::NS + lj;
 
-    auto compute = [&](const float* buf) DCSCN_INL {
-        const float* As = buf + a_lane;
-        const float* Bs = buf + b_lane;
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(PRIO);
-        // one 4-channel MFMA step per iteration; NOT unrolled across steps so that only one step's raw
-        // patch / transformed operands are live next to the 16*NT accumulators
-#pragma unroll 1
-        for (int ks = 0; ks < G::KQ; ++ks, As += 4 * G::PS, Bs += 4 * G::NS) {
-            // raw patch d[i][j], i = row, j = column (each row: 4 consecutive floats, 8-byte aligned)
-            float d[4][4];
-            static_for<0, 4>([&](auto i_) DCSCN_INL {
-                constexpr int i = decltype(i_)::value;
-                const float2 lo = *reinterpret_cast<const float2*>(As + i * G::HTW);
-                const float2 hi = *reinterpret_cast<const float2*>(As + i * G::HTW + 2);
-                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
-            });
-            // V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-            float r[4][4], v[16];
-            static_for<0, 4>([&](auto j_) DCSCN_INL {
-                constexpr int j = decltype(j_)::value;
-                r[0][j] = d[0][j] - d[2][j];
-                r[1][j] = d[1][j] + d[2][j];
-                r[2][j] = d[2][j] - d[1][j];
-                r[3][j] = d[1][j] - d[3][j];
-            });
-            static_for<0, 4>([&](auto x_) DCSCN_INL {
-                constexpr int x = decltype(x_)::value;
-                v[4 * x + 0] = r[x][0] - r[x][2];
-                v[4 * x + 1] = r[x][1] + r[x][2];
-                v[4 * x + 2] = r[x][2] - r[x][1];
-                v[4 * x + 3] = r[x][1] - r[x][3];
-            });
+    // raw 4x4 patch of this lane's (tile, channel) for k-step `ks` -> transformed operands v[16]
+    auto read_raw = [&](const float* As, float (&d)[4][4]) DCSCN_INL {
+        static_for<0, 4>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            const float2 lo = *reinterpret_cast<const float2*>(As + i * G::HTW);
+            const float2 hi = *reinterpret_cast<const float2*>(As + i * G::HTW + 2);
+            d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+        });
+    };
+    auto transform = [&](const float (&d)[4][4], float (&v)[16]) DCSCN_INL {
+        // V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+        float r[4][4];
+        static_for<0, 4>([&](auto j_) DCSCN_INL {
+            constexpr int j = decltype(j_)::value;
+            r[0][j] = d[0][j] - d[2][j];
+            r[1][j] = d[1][j] + d[2][j];
+            r[2][j] = d[2][j] - d[1][j];
+            r[3][j] = d[1][j] - d[3][j];
+        });
+        static_for<0, 4>([&](auto x_) DCSCN_INL {
+            constexpr int x = decltype(x_)::value;
+            v[4 * x + 0] = r[x][0] - r[x][2];
+            v[4 * x + 1] = r[x][1] + r[x][2];
+            v[4 * x + 2] = r[x][2] - r[x][1];
+            v[4 * x + 3] = r[x][1] - r[x][3];
+        });
+    };
+    // the 16*NTV MFMAs of one k-step; filter operands read PF frequencies ahead (PF = 0: hipcc's order,
+    // which keeps a single operand pair in flight and stalls on every frequency)
+    auto mfma_step = [&](const float* Bs, const float (&v)[16]) DCSCN_INL {
+        if constexpr (PF == 0) {
             static_for<0, 16>([&](auto f_) DCSCN_INL {
                 constexpr int f = decltype(f_)::value;
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
@@ -187,6 +186,67 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
                     acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[f], acc[f][n], 0, 0, 0);
                 });
             });
+        } else {
+            float wq[PF + 1][NTV];
+            static_for<0, PF>([&](auto p_) DCSCN_INL {
+                constexpr int pf = decltype(p_)::value;
+                static_for<0, NTV>([&](auto n_) DCSCN_INL {
+                    constexpr int n = decltype(n_)::value;
+                    wq[pf][n] = Bs[(pf * KC) * G::NS + n * 16];
+                });
+            });
+            static_for<0, 16>([&](auto f_) DCSCN_INL {
+                constexpr int f = decltype(f_)::value;
+                if constexpr (f + PF < 16) {
+                    static_for<0, NTV>([&](auto n_) DCSCN_INL {
+                        constexpr int n = decltype(n_)::value;
+                        wq[(f + PF) % (PF + 1)][n] = Bs[((f + PF) * KC) * G::NS + n * 16];
+                    });
+                    __builtin_amdgcn_sched_group_barrier(0x100, NTV, 0);   // DS reads of f + PF
+                }
+                static_for<0, NTV>([&](auto n_) DCSCN_INL {
+                    constexpr int n = decltype(n_)::value;
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[f % (PF + 1)][n], v[f], acc[f][n], 0, 0, 0);
+                });
+                __builtin_amdgcn_sched_group_barrier(0x8, NTV, 0);          // MFMAs of f
+            });
+        }
+    };
+
+    auto compute = [&](const float* buf) DCSCN_INL {
+        const float* As = buf + a_lane;
+        const float* Bs = buf + b_lane;
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+        if constexpr (VPIPE && G::KQ > 1) {
+            // k-steps fully unrolled; the raw patch of step ks+1 is read and transformed while the MFMAs
+            // of step ks run (needs a second operand set: 16 more VGPRs)
+            float va[16], vb[16];
+            {
+                float d[4][4];
+                read_raw(As, d);
+                transform(d, va);
+            }
+            static_for<0, G::KQ>([&](auto ks_) DCSCN_INL {
+                constexpr int ks = decltype(ks_)::value;
+                float d[4][4];
+                if constexpr (ks + 1 < G::KQ) read_raw(As + (ks + 1) * 4 * G::PS, d);
+                if constexpr (ks % 2 == 0) mfma_step(Bs + ks * 4 * G::NS, va);
+                else mfma_step(Bs + ks * 4 * G::NS, vb);
+                if constexpr (ks + 1 < G::KQ) {
+                    if constexpr (ks % 2 == 0) transform(d, vb);
+                    else transform(d, va);
+                }
+            });
+        } else {
+            // one 4-channel MFMA step per iteration; NOT unrolled across steps so that only one step's
+            // raw patch / transformed operands are live next to the 16*NT accumulators
+#pragma unroll 1
+            for (int ks = 0; ks < G::KQ; ++ks, As += 4 * G::PS, Bs += 4 * G::NS) {
+                float d[4][4], v[16];
+                read_raw(As, d);
+                transform(d, v);
+                mfma_step(Bs, v);
+            }
         }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
@@ -384,15 +444,15 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
 
 // WAVES waves per workgroup = a (4*WAVES) x 16 output-pixel tile; launch_bounds' second argument is
 // waves per SIMD: WPS workgroups of 4 waves, or WPS/2 workgroups of 8.
-template <int NT, int KC, int WPS, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false, int PRIO = 0>
+template <int NT, int KC, int WPS, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false, int PRIO = 0, int PF = 0, bool VPIPE = false>
 __global__ __launch_bounds__(64 * WAVES, WPS) void conv_wino(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nt_valid = (blockIdx.y == gridDim.y - 1) ? a.nt_last : NT;   // block uniform
-    if (nt_valid == NT) conv_wino_body<NT, NT, KC, DB, ABLATE, WAVES, DMA, PRIO>(a, smem);
+    if (nt_valid == NT) conv_wino_body<NT, NT, KC, DB, ABLATE, WAVES, DMA, PRIO, PF, VPIPE>(a, smem);
     else if constexpr (NT >= 2) {
-        if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC, DB, ABLATE, WAVES, DMA, PRIO>(a, smem);
+        if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC, DB, ABLATE, WAVES, DMA, PRIO, PF, VPIPE>(a, smem);
         else if constexpr (NT >= 3) {
-            if (nt_valid == NT - 2) conv_wino_body<NT, NT - 2, KC, DB, ABLATE, WAVES, DMA, PRIO>(a, smem);
+            if (nt_valid == NT - 2) conv_wino_body<NT, NT - 2, KC, DB, ABLATE, WAVES, DMA, PRIO, PF, VPIPE>(a, smem);
         }
     }
 }

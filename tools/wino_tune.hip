@@ -95,7 +95,7 @@ static float time_kernel(K kern, dim3 grid, size_t lds, const ConvArgs& a, int r
 
 static float *g_in, *g_ref, *g_out, *g_w, *g_bias;
 
-template <int MT, int NTD, int NTW, int KCW, int WPSW, bool DBW = false, int ABL = 0, int WAVES = 4, bool DMA = false, int PRIO = 0>
+template <int MT, int NTD, int NTW, int KCW, int WPSW, bool DBW = false, int ABL = 0, int WAVES = 4, bool DMA = false, int PRIO = 0, int PF = 0, bool VPIPE = false>
 void run(const Layer& L) {
     const int cin_phys = (L.cin + 3) & ~3;
     std::vector<float> w = rand_vec((size_t)9 * L.cin * L.cout, 777, 0.2f);
@@ -132,7 +132,7 @@ void run(const Layer& L) {
         a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gw::TH - 1) / Gw::TH;
         a.out0 = OutDesc{g_out, L.out_stride, L.out_off, (L.cout + 3) & ~3};
         a.out1 = a.out0;
-        auto kern = conv_wino<NTW, KCW, WPSW, DBW, ABL, WAVES, DMA, PRIO>;
+        auto kern = conv_wino<NTW, KCW, WPSW, DBW, ABL, WAVES, DMA, PRIO, PF, VPIPE>;
         const size_t lds = ((DBW || DMA) ? 2 : 1) * (size_t)Gw::BUF * sizeof(float) * (size_t)g_lds_mul;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int occ = 0;
@@ -151,8 +151,8 @@ void run(const Layer& L) {
                 maxd = std::fmax(maxd, std::fabs((double)r[i] - o[i]));
                 maxv = std::fmax(maxv, std::fabs((double)r[i]));
             }
-        printf("%-8s %4d->%-4d wino W%d DB%d DMA%d P%d ABL%d NT%d KC%d WPS%d tiles%d lds %5.1f KB occ %d  %8.3f ms  %7.2f TFLOP/s(alg)  max|diff| %.3g (max|ref| %.3g)\n",
-               L.name, L.cin, L.cout, WAVES, (int)DBW, (int)DMA, PRIO, ABL, NTW, KCW, WPSW, ntiles, lds / 1024.0, occ, ms, flop / (ms * 1e-3) / 1e12, maxd, maxv);
+        printf("%-8s %4d->%-4d wino W%d DB%d DMA%d P%d PF%d VP%d ABL%d NT%d KC%d WPS%d tiles%d lds %5.1f KB occ %d  %8.3f ms  %7.2f TFLOP/s(alg)  max|diff| %.3g (max|ref| %.3g)\n",
+               L.name, L.cin, L.cout, WAVES, (int)DBW, (int)DMA, PRIO, PF, (int)VPIPE, ABL, NTW, KCW, WPSW, ntiles, lds / 1024.0, occ, ms, flop / (ms * 1e-3) / 1e12, maxd, maxv);
     }
     fflush(stdout);
 }
@@ -180,7 +180,10 @@ int main(int argc, char** argv) {
     const Layer cnn8{"CNN8", 97, 86, 1316, 984, 1316, 1084};
     const Layer cnn12{"CNN12", 57, 48, 1316, 1248, 1316, 1268};
     const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
-    run<2, 11, 3, 4, 2>(cnn2);
-    run<2, 11, 3, 4, 2, false, 3>(cnn2);
+    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 2>(cnn2);
+    run<2, 11, 2, 8, 2, false, 0, 4, false, 0, 2, true>(cnn2);
+    run<2, 11, 2, 8, 2, false, 0, 4, false, 0, 0, true>(cnn2);
+    run<2, 11, 2, 8, 2, true, 0, 4, false, 0, 2, true>(cnn2);
+    run<2, 11, 3, 8, 2, false, 0, 4, false, 0, 1, true>(cnn2);
     return 0;
 }
