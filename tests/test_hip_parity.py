@@ -155,3 +155,27 @@ def test_errors_are_reported_not_fatal(oracle):
         engine.Engine(oracle.make_config(pixel_shuffler=False))
     with pytest.raises(engine.EngineError):
         engine.Engine(dict(scale=5))
+
+
+def test_full_size_bench_workload(oracle):
+    """BASELINE.json configs[2] at its full size (L12_F196to48 x2, 1024 patches of 48x48): the oracle needs
+    ~4 s per patch pair, so 6 sampled patches are checked against it directly and the rest through
+    size-independent properties -- every patch depends on its own input only (a batch of 1024 equals the
+    same patches run in other batch compositions, bit for bit), runs are deterministic, outputs finite."""
+    cfg = oracle.make_config()
+    weights = oracle.synthetic_weights(cfg, seed=0)
+    n = 1024
+    rng = np.random.default_rng(11)
+    x = rng.uniform(0, 255, (n, 48, 48, 1)).astype(np.float32)
+    x2 = rng.uniform(0, 255, (n, 96, 96, 1)).astype(np.float32)
+    with _engine(cfg, weights) as eng:
+        y = eng.forward(x, x2)
+        assert np.isfinite(y).all()
+        assert np.array_equal(y, eng.forward(x, x2))                       # deterministic
+        eng.set_option("sub_batch_pixels", 100 * 48 * 48)                   # 11 ragged passes (100 x 10 + 24)
+        assert np.array_equal(y, eng.forward(x, x2))
+        perm = rng.permutation(n)[:200]
+        assert np.array_equal(y[perm], eng.forward(x[perm], x2[perm]))     # other batch composition
+    pick = [0, 1, 511, 512, 1000, 1023]
+    ref = oracle.forward(cfg, weights, x[pick], x2[pick], dtype=np.float64)
+    assert float(np.max(np.abs(y[pick] - ref))) <= MAX_ABS_TOL
