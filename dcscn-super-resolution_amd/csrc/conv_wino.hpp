@@ -182,7 +182,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
                 constexpr int f = decltype(f_)::value;
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
                     constexpr int n = decltype(n_)::value;
-                    const float wv = Bs[(f * KC) * G::NS + n * 16];
+                    const float wv = ABLATE == 6 ? breg[0].x : Bs[(f * KC) * G::NS + n * 16];   // 6: tuner only
                     acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[f], acc[f][n], 0, 0, 0);
                 });
             });
@@ -243,8 +243,13 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
 #pragma unroll 1
             for (int ks = 0; ks < G::KQ; ++ks, As += 4 * G::PS, Bs += 4 * G::NS) {
                 float d[4][4], v[16];
-                read_raw(As, d);
-                transform(d, v);
+                if constexpr (ABLATE == 5) {
+                    // tuner only: no raw read / transform (operands forged from a register)
+                    static_for<0, 16>([&](auto f_) DCSCN_INL { v[decltype(f_)::value] = areg[0].x + (float)decltype(f_)::value; });
+                } else {
+                    read_raw(As, d);
+                    transform(d, v);
+                }
                 mfma_step(Bs, v);
             }
         }
