@@ -81,6 +81,8 @@ struct Op {
     int dw_w = -1;                  // depthwise filter tensor (OP_DW, fused-depthwise OP_CONV, OP_COUT1 of a separable conv)
     int dwk = 0;                    // fused depthwise kernel size of an OP_CONV (0 = plain conv)
     float out_scale = 1.0f;         // OP_COUT1: pointwise scalar of a separable 1->1 conv
+    int tconv_s = 0;                // > 0: the op is tf.nn.conv2d_transpose with this stride, run as its
+                                    // equivalent 3x3 conv to s*s*C channels + depth_to_space (see add_tconv)
     // output
     int out_buf[2] = {EXT_Y, EXT_Y}, out_off[2] = {0, 0}, out_width[2] = {0, 0};
     int split = 1 << 30;
@@ -362,6 +364,54 @@ void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_nam
     h->ops.push_back(op);
 }
 
+// build_transposed_conv (tf_graph.py:219-236): tf.nn.conv2d_transpose(x, W[k,k,C,C], stride s, SAME) with
+// k = 2s - s%2, no bias, no activator.  Output pixel (s*h0 + a, s*w0 + b) only receives input pixels
+// (h0 + dy, w0 + dx) with dy, dx in {-1, 0, 1}: filter tap ky = a + pt - s*dy (pt = (k - s) / 2) when that
+// lies in [0, k).  So the op IS a 3x3 SAME conv from C to s*s*C channels followed by depth_to_space(s):
+//   W3[dy+1][dx+1][ic][(a*s + b)*C + oc] = W[a + pt - s*dy][b + pt - s*dx][oc][ic]   (0 where out of range)
+// and runs on the same kernels as the pixel shuffler (products identical, the added terms are exact zeros).
+void add_tconv(dcscn_ctx* h, const Src& src, int s) {
+    const int C = src.cin;
+    const int k = 2 * s - s % 2;
+    dcscn_layer_info li{};
+    snprintf(li.name, sizeof li.name, "Up-TCNN");
+    li.kernel_size = k;
+    li.in_channels = C;
+    li.out_channels = C;
+    li.resolution = src.res;
+    const int64_t r2 = (int64_t)src.res * src.res;
+    li.macs_per_lr_pixel = r2 * k * k * C * (int64_t)C;
+    h->layers.push_back(li);
+
+    Op op;
+    op.kind = OP_CONV;
+    op.name = "Up-TCNN";
+    op.ks = 3;
+    op.cin = C;
+    op.cout = C;
+    op.res = src.res;
+    op.act = ACT_NONE;
+    op.tconv_s = s;
+    ColSeg seg;
+    seg.w = add_tensor(h, "Up-TCNN/Tconv_W", {k, k, C, C});
+    seg.cout = s * s * C;
+    op.segs.push_back(seg);
+    op.in_buf = src.buf;
+    op.in_off = src.off;
+    op.cin_phys = src.cin_phys;
+    op.chan_map = src.map;
+    const int ub = new_buf(h, pad4(C), src.res * s);
+    op.out_buf[0] = ub;
+    op.out_off[0] = 0;
+    op.out_width[0] = s * s * C;
+    op.ps = s;
+    op.ps_c = C;
+    op.vec4 = C % 4 == 0;
+    op.macs = li.macs_per_lr_pixel;
+    op.bytes = 4 * r2 * (src.cin_phys + (int64_t)s * s * C);
+    h->ops.push_back(op);
+}
+
 int build_graph(dcscn_ctx* h) {
     const dcscn_config& c = h->cfg;
     const bool ds = c.depthwise_separable != 0;
@@ -461,24 +511,29 @@ int build_graph(dcscn_ctx* h) {
         src = identity_src(t2, 0, c.filters, 1);
     }
 
-    // upsampling, DCSCN.py:293-311 + tf_graph.py:238-249
-    const int ps_out = c.pixel_shuffler_filters != 0 ? c.pixel_shuffler_filters : src.cin;
-    struct Stage { const char* name; int s; int cout; };
-    std::vector<Stage> stages;
-    if (c.scale == 4) {
-        stages.push_back({"Up-PS", 2, src.cin});
-        stages.push_back({"Up-PS2", 2, ps_out});
+    // upsampling, DCSCN.py:293-311 + tf_graph.py:219-249
+    if (c.pixel_shuffler) {
+        const int ps_out = c.pixel_shuffler_filters != 0 ? c.pixel_shuffler_filters : src.cin;
+        struct Stage { const char* name; int s; int cout; };
+        std::vector<Stage> stages;
+        if (c.scale == 4) {
+            stages.push_back({"Up-PS", 2, src.cin});
+            stages.push_back({"Up-PS2", 2, ps_out});
+        } else {
+            stages.push_back({"Up-PS", c.scale, ps_out});
+        }
+        for (const Stage& st : stages) {
+            const int ub = new_buf(h, pad4(st.cout), src.res * st.s);
+            Dst d;
+            d.buf = ub; d.off = 0; d.width = st.s * st.s * st.cout;
+            d.ps = st.s; d.ps_c = st.cout;
+            const std::string var = std::string(st.name) + "/" + st.name + "_CNN";
+            add_conv(h, var, std::string(st.name) + "_CNN", src, k, st.s * st.s * st.cout, true, DCSCN_ACT_NONE, ds, d, &dw_buf);
+            src = identity_src(ub, 0, st.cout, src.res * st.s);
+        }
     } else {
-        stages.push_back({"Up-PS", c.scale, ps_out});
-    }
-    for (const Stage& st : stages) {
-        const int ub = new_buf(h, pad4(st.cout), src.res * st.s);
-        Dst d;
-        d.buf = ub; d.off = 0; d.width = st.s * st.s * st.cout;
-        d.ps = st.s; d.ps_c = st.cout;
-        const std::string var = std::string(st.name) + "/" + st.name + "_CNN";
-        add_conv(h, var, std::string(st.name) + "_CNN", src, k, st.s * st.s * st.cout, true, DCSCN_ACT_NONE, ds, d, &dw_buf);
-        src = identity_src(ub, 0, st.cout, src.res * st.s);
+        add_tconv(h, src, c.scale);
+        src = identity_src(h->ops.back().out_buf[0], 0, src.cin, src.res * c.scale);
     }
 
     // reconstruction convs at HR, DCSCN.py:313-323
@@ -561,6 +616,26 @@ int finalize_op(dcscn_ctx* h, Op& op) {
         return rc;
     }
 
+    // transposed conv: materialise the equivalent 3x3 filter [3][3][C][s*s*C] (see add_tconv)
+    TensorSpec derived;
+    if (op.tconv_s > 0) {
+        const TensorSpec& t = h->tensors[op.segs[0].w];      // [k, k, out C, in C]
+        const int sc = op.tconv_s, kk = (int)t.shape[0], C = (int)t.shape[2], pt = (kk - sc) / 2, co = sc * sc * C;
+        derived.data.assign((size_t)9 * C * co, 0.0f);
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+                for (int a2 = 0; a2 < sc; ++a2)
+                    for (int b2 = 0; b2 < sc; ++b2) {
+                        const int ky = a2 + pt - sc * dy, kx = b2 + pt - sc * dx;
+                        if (ky < 0 || ky >= kk || kx < 0 || kx >= kk) continue;
+                        for (int ic = 0; ic < C; ++ic)
+                            for (int oc = 0; oc < C; ++oc)
+                                derived.data[(((size_t)(dy + 1) * 3 + (dx + 1)) * C + ic) * co + (size_t)(a2 * sc + b2) * C + oc] =
+                                    t.data[(((size_t)ky * kk + kx) * C + oc) * C + ic];
+                    }
+    }
+    const TensorSpec* w_override = op.tconv_s > 0 ? &derived : nullptr;
+
     // OP_CONV: dense [tap][k_phys][conv channel] -> [n_tile][chunk][tap][kk][NS]
     int ctot = 0;
     for (const ColSeg& s : op.segs) ctot = std::max(ctot, s.dst + s.cout);
@@ -586,7 +661,7 @@ int finalize_op(dcscn_ctx* h, Op& op) {
         std::vector<float> pack((size_t)op.n_tiles * op.n_chunks * chunk_floats + 2048, 0.0f);
         std::vector<float> bias(op.ctot, 0.0f), alpha(op.ctot, 0.0f);
         const ColSeg& sg = op.segs[0];
-        const TensorSpec& tw = h->tensors[sg.w];            // [3, 3, cin, cout]
+        const TensorSpec& tw = w_override ? *w_override : h->tensors[sg.w];   // [3, 3, cin, cout]
         const int cin = (int)op.chan_map.size();
         static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         for (int ci = 0; ci < cin; ++ci) {
@@ -637,7 +712,7 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     std::vector<float> pack((size_t)op.n_tiles * op.n_chunks * chunk_floats, 0.0f);
     std::vector<float> bias(op.ctot, 0.0f), alpha(op.ctot, 0.0f);
     for (const ColSeg& s : op.segs) {
-        const TensorSpec& tw = h->tensors[s.w];             // [ks, ks, cin, cout] (or [1,1,cin,cout])
+        const TensorSpec& tw = w_override ? *w_override : h->tensors[s.w];   // [ks, ks, cin, cout] (or [1,1,cin,cout])
         const int cin = (int)op.chan_map.size();
         for (int t = 0; t < taps; ++t)
             for (int ci = 0; ci < cin; ++ci) {
@@ -886,7 +961,8 @@ int dcscn_create(const dcscn_config* cfg, int device, dcscn_handle* out) {
     if (c.layers > 1 && !(c.filters_decay_gamma > 0.0)) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "filters_decay_gamma must be > 0");
     if (c.cnn_size != 3 && c.cnn_size != 1) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "cnn_size %d (supported: 3, 1)", c.cnn_size);
     if (c.channels != 1) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "channels %d (the reference itself only supports 1)", c.channels);
-    if (!c.pixel_shuffler) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "transposed-conv upsampler (pixel_shuffler=false) is not implemented");
+    if (!c.pixel_shuffler && c.depthwise_separable)
+        return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "transposed-conv upsampler together with depthwise_separable is not implemented");
     if (c.batch_norm) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "batch_norm is not implemented");
     float dummy;
     if (kernel_act(c.activator, &dummy) < 0) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "Not implemented activator:%d", c.activator);

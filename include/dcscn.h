@@ -75,7 +75,8 @@ typedef struct dcscn_config {
     int32_t reconstruct_layers;     /* max(flag, 1) applied inside, DCSCN.py:42 */
     int32_t reconstruct_filters;
     int32_t activator;              /* dcscn_activator */
-    int32_t pixel_shuffler;         /* must be 1 (transposed-conv upsampler not implemented) */
+    int32_t pixel_shuffler;         /* 1: pixel shuffler (tf_graph.py:238-249); 0: transposed conv "Up-TCNN"
+                                       (tf_graph.py:219-236), run as its equivalent 3x3 conv + depth_to_space */
     int32_t pixel_shuffler_filters; /* 0 = same as input channels */
     int32_t depthwise_separable;
     int32_t channels;               /* must be 1 */

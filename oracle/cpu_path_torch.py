@@ -23,7 +23,9 @@ class TorchCpuModel:
         for name, arr in weights.items():
             t = torch.from_numpy(np.ascontiguousarray(arr)).to(dtype)
             leaf = name.rsplit("/", 1)[-1]
-            if leaf in ("conv_W", "pointwise_W"):
+            if leaf == "Tconv_W":
+                t = t.permute(3, 2, 0, 1).contiguous()            # [kh,kw,out,in] -> [in,out,kh,kw]
+            elif leaf in ("conv_W", "pointwise_W"):
                 t = t.permute(3, 2, 0, 1).contiguous()            # HWIO -> OIHW
             elif leaf == "depthwise_W":
                 t = t.permute(2, 3, 0, 1).contiguous()            # [k,k,C,1] -> [C,1,k,k]
@@ -73,6 +75,10 @@ class TorchCpuModel:
                 # TF channel order: (i*b + j)*co + c  ->  [n, co, hh*b, ww*b]
                 h = h.view(n, b, b, co, hh, ww).permute(0, 3, 4, 1, 5, 2).reshape(n, co, hh * b, ww * b)
                 t[op["dst"]] = h
+            elif kind == "conv_transpose":
+                sc = op["scale"]
+                w = self.w[op["var"] + "/Tconv_W"]
+                t[op["dst"]] = F.conv_transpose2d(t[op["src"]], w, stride=sc, padding=(w.shape[2] - sc) // 2)
             elif kind == "add":
                 t[op["dst"]] = t[op["srcs"][0]] + t[op["srcs"][1]]
         return t["y_"].permute(0, 2, 3, 1).contiguous().numpy()

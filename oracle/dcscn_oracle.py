@@ -14,12 +14,13 @@ TF ops are restated from their published semantics:
   tf.nn.separable_conv2d = depthwise k x k SAME (channel multiplier 1) then 1x1    (tf_graph.py:161)
   tf.depth_to_space(block b): out[n, h*b+i, w*b+j, c] = in[n, h, w, (i*b+j)*C + c] (tf_graph.py:248)
   PReLU as written: relu(x) + alpha * (x - |x|) * 0.5                              (tf_graph.py:94)
+  tf.nn.conv2d_transpose stride s, SAME, filter [k, k, out, in]                    (tf_graph.py:227)
   tf.concat axis 3, tf.add                                                         (DCSCN.py:259,281,325)
 
 PARITY PINNING: the reference ships no tests and no golden vectors, and TF
 cannot run here, so bit-level parity with the reference binary is UNPINNED.  What pins this oracle
 is the reference's published PSNR table (README.md:55-65, 2 decimals) reproduced with the shipped
-checkpoints on the shipped Set5/Set14 images (tests/test_oracle_psnr.py).
+checkpoints on the shipped Set5 images (tests/test_oracle_golden.py).
 """
 
 import math
@@ -108,15 +109,20 @@ def build_topology(cfg):
         src = conv("C", "H_concat", 1, total, cfg["filters"], True, act, ds)
         cin = cfg["filters"]
 
-    # upsampling (DCSCN.py:293-311, tf_graph.py:238-249)
-    if not cfg["pixel_shuffler"]:
-        raise NotImplementedError("transposed-conv upsampler (tf_graph.py:219-236) is not restated")
-    cout = cfg["pixel_shuffler_filters"] if cfg["pixel_shuffler_filters"] != 0 else cin
-    stages = [("Up-PS", 2, cin), ("Up-PS2", 2, cout)] if cfg["scale"] == 4 else [("Up-PS", cfg["scale"], cout)]
-    for name, s, c_out in stages:
-        conv(name + "_CNN", src, k, cin, s * s * c_out, True, None, ds, var=name + "/" + name + "_CNN")
-        ops.append(dict(op="depth_to_space", src=name + "_CNN", dst=name, block=s))
-        src, cin = name, c_out
+    # upsampling (DCSCN.py:293-311, tf_graph.py:219-249)
+    if cfg["pixel_shuffler"]:
+        cout = cfg["pixel_shuffler_filters"] if cfg["pixel_shuffler_filters"] != 0 else cin
+        stages = [("Up-PS", 2, cin), ("Up-PS2", 2, cout)] if cfg["scale"] == 4 else [("Up-PS", cfg["scale"], cout)]
+        for name, s, c_out in stages:
+            conv(name + "_CNN", src, k, cin, s * s * c_out, True, None, ds, var=name + "/" + name + "_CNN")
+            ops.append(dict(op="depth_to_space", src=name + "_CNN", dst=name, block=s))
+            src, cin = name, c_out
+    else:
+        # build_transposed_conv("Up-TCNN", H[-1], scale, channels): one stage for any scale, no bias, no
+        # activator, filter [k, k, C, C] with k = 2 s - s % 2 (utilty.py:377-390)
+        ops.append(dict(op="conv_transpose", name="Up-TCNN", var="Up-TCNN", src=src, dst="Up-TCNN",
+                        scale=cfg["scale"], channels=cin))
+        src = "Up-TCNN"
 
     # reconstruction convs at HR (DCSCN.py:313-323); extra layers always use build_conv (never DS)
     rl = cfg["reconstruct_layers"]
@@ -132,6 +138,10 @@ def variable_shapes(cfg):
     """``{checkpoint variable name: shape}`` the topology consumes (names as in tf_graph.py:117-216)."""
     shapes = {}
     for op in build_topology(cfg):
+        if op["op"] == "conv_transpose":
+            ks = 2 * op["scale"] - op["scale"] % 2
+            shapes[op["var"] + "/Tconv_W"] = (ks, ks, op["channels"], op["channels"])
+            continue
         if op["op"] != "conv":
             continue
         v, k, cin, cout = op["var"], op["k"], op["cin"], op["cout"]
@@ -153,6 +163,10 @@ def macs_per_lr_pixel(cfg):
     for op in build_topology(cfg):
         if op["op"] == "depth_to_space":
             res *= op["block"] ** 2
+        elif op["op"] == "conv_transpose":
+            ks = 2 * op["scale"] - op["scale"] % 2
+            total += res * ks * ks * op["channels"] ** 2        # every input pixel meets every filter tap
+            res *= op["scale"] ** 2
         elif op["op"] == "conv":
             k, cin, cout = op["k"], op["cin"], op["cout"]
             total += res * ((k * k * cin + cin * cout) if op["ds"] else k * k * cin * cout)
@@ -175,7 +189,19 @@ def synthetic_weights(cfg, seed=0):
     for name in sorted(shapes):
         shape = shapes[name]
         leaf = name.rsplit("/", 1)[-1]
-        if leaf in ("conv_W", "depthwise_W", "pointwise_W"):
+        if leaf == "Tconv_W":
+            # bilinear initialiser of the reference (utilty.py:366-390) plus seeded noise so that every
+            # (out, in) channel pair and every tap is exercised
+            size = shape[0]
+            factor = (size + 1) // 2
+            center = factor - 1 if size % 2 == 1 else factor - 0.5
+            og = np.ogrid[:size, :size]
+            bil = (1 - abs(og[0] - center) / factor) * (1 - abs(og[1] - center) / factor)
+            w = 0.05 * rng.standard_normal(shape)
+            for i in range(shape[2]):
+                w[:, :, i, i] += bil
+            weights[name] = w.astype(np.float32)
+        elif leaf in ("conv_W", "depthwise_W", "pointwise_W"):
             fan_in = shape[0] * shape[1] * shape[2]
             std = math.sqrt(2.0 / fan_in)
             w = rng.standard_normal(shape)
@@ -227,6 +253,21 @@ def depthwise_conv2d_same(x, w):
         for dx in range(kw):
             out += xp[:, dy:dy + h, dx:dx + wd, :] * w[dy, dx, :, 0]
     return out
+
+
+def conv2d_transpose_same(x, w, s):
+    """tf.nn.conv2d_transpose(x, w, [N, sH, sW, C], strides s, padding SAME) (tf_graph.py:227): filter
+    [kh, kw, out_c, in_c]; out[n, h*s + ky - pt, w*s + kx - pl, oc] += x[n, h, w, ic] * w[ky, kx, oc, ic]
+    with pt = pl = (k - s) // 2 (the SAME padding of the forward conv this op is the gradient of)."""
+    kh, kw, oc, ic = w.shape
+    n, h, wd, c = x.shape
+    assert c == ic
+    pt = (kh - s) // 2
+    big = np.zeros((n, (h - 1) * s + kh, (wd - 1) * s + kw, oc), dtype=x.dtype)
+    for ky in range(kh):
+        for kx in range(kw):
+            big[:, ky:ky + (h - 1) * s + 1:s, kx:kx + (wd - 1) * s + 1:s, :] += x @ w[ky, kx].T
+    return np.ascontiguousarray(big[:, pt:pt + h * s, pt:pt + wd * s, :])
 
 
 def activate(x, kind, alpha=None):
@@ -285,6 +326,8 @@ def forward(cfg, weights, x, x2, dtype=np.float64, return_intermediates=False):
             t[op["dst"]] = np.concatenate([t[s] for s in op["srcs"]], axis=3)
         elif kind == "depth_to_space":
             t[op["dst"]] = depth_to_space(t[op["src"]], op["block"])
+        elif kind == "conv_transpose":
+            t[op["dst"]] = conv2d_transpose_same(t[op["src"]], weights[op["var"] + "/Tconv_W"].astype(dtype), op["scale"])
         elif kind == "add":
             t[op["dst"]] = t[op["srcs"][0]] + t[op["srcs"][1]]
         else:

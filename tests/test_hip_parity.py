@@ -99,6 +99,11 @@ def test_sub_batching_is_transparent(oracle):
     dict(layers=2, filters=8, min_filters=8, cnn_size=1),
     dict(layers=3, filters=16, min_filters=8, depthwise_separable=True, scale=2),
     dict(layers=3, filters=16, min_filters=8, depthwise_separable=True, use_nin=False, scale=3),
+    # transposed-conv upsampler (tf_graph.py:219-236), k = 4 / 5 / 8
+    dict(layers=3, filters=16, min_filters=8, pixel_shuffler=False),
+    dict(layers=3, filters=16, min_filters=8, pixel_shuffler=False, scale=3, nin_filters=9, nin_filters2=5),
+    dict(layers=2, filters=12, min_filters=8, pixel_shuffler=False, scale=4, reconstruct_layers=2, reconstruct_filters=8),
+    dict(layers=2, filters=40, min_filters=36, pixel_shuffler=False, use_nin=False),
 ])
 def test_flag_surface(oracle, variant):
     _check(oracle, str(variant), variant, 2, 20, 28)
@@ -151,8 +156,9 @@ def test_errors_are_reported_not_fatal(oracle):
     eng.load_weights(weights)
     assert eng.forward(x, x2).shape == (1, 16, 16, 1)
     eng.close()
-    with pytest.raises(engine.EngineError):
-        engine.Engine(oracle.make_config(pixel_shuffler=False))
+    with pytest.raises(engine.EngineError) as e:
+        engine.Engine(oracle.make_config(pixel_shuffler=False, depthwise_separable=True))
+    assert e.value.status == 2
     with pytest.raises(engine.EngineError):
         engine.Engine(dict(scale=5))
 
