@@ -177,7 +177,18 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     // the 16*NTV MFMAs of one k-step; filter operands read PF frequencies ahead (PF = 0: hipcc's order,
     // which keeps a single operand pair in flight and stalls on every frequency)
     auto mfma_step = [&](const float* Bs, const float (&v)[16]) DCSCN_INL {
-        if constexpr (PF == 0) {
+        if constexpr (PF < 0) {
+            // tuner only: let LLVM's IGroupLP strategy (-PF - 1) interleave DS reads and MFMAs
+            __builtin_amdgcn_iglp_opt(-PF - 1);
+            static_for<0, 16>([&](auto f_) DCSCN_INL {
+                constexpr int f = decltype(f_)::value;
+                static_for<0, NTV>([&](auto n_) DCSCN_INL {
+                    constexpr int n = decltype(n_)::value;
+                    const float wv = Bs[(f * KC) * G::NS + n * 16];
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[f], acc[f][n], 0, 0, 0);
+                });
+            });
+        } else if constexpr (PF == 0) {
             static_for<0, 16>([&](auto f_) DCSCN_INL {
                 constexpr int f = decltype(f_)::value;
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
@@ -187,7 +198,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
                 });
             });
         } else {
-            float wq[PF + 1][NTV];
+            float wq[(PF > 0 ? PF : 0) + 1][NTV];
             static_for<0, PF>([&](auto p_) DCSCN_INL {
                 constexpr int pf = decltype(p_)::value;
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {

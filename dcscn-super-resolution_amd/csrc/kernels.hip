@@ -91,8 +91,8 @@ static hipError_t wino_launch_one(const ConvArgs& a, int n_groups, hipStream_t s
     using G = WinoGeom<NT, kWinoKC>;
     const size_t lds = (size_t)G::BUF * sizeof(float);
     const dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)n_groups);
-    // single LDS buffer, 4 waves, filter reads software-pipelined two frequencies ahead (tools/wino_tune.hip)
-    hipLaunchKernelGGL((conv_wino<NT, kWinoKC, 2, false, 0, 4, false, 0, 2>), grid, dim3(256), lds, stream, a);
+    // single LDS buffer, 4 waves, filter reads software-pipelined three frequencies ahead (tools/wino_tune.hip)
+    hipLaunchKernelGGL((conv_wino<NT, kWinoKC, 2, false, 0, 4, false, 0, 3>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
