@@ -15,8 +15,9 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_NAME = "libdcscn_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
-SOURCES = ["api.hip", "kernels.hip"]
-HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(INCLUDE, "dcscn.h")]
+SOURCES = ["api.hip", "kernels.hip", "conv_k1.hip", "conv_k3.hip", "conv_wino.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "conv_igemm.hpp", "conv_wino.hpp", "conv_variants.hpp")] + \
+          [os.path.join(INCLUDE, "dcscn.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -227,7 +227,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     auto compute = [&](const float* buf) DCSCN_INL {
         const float* As = buf + a_lane;
         const float* Bs = buf + b_lane;
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+        if constexpr (PRIO > 0 && PRIO < 10) __builtin_amdgcn_s_setprio(PRIO);
         if constexpr (VPIPE && G::KQ > 1) {
             // k-steps fully unrolled; the raw patch of step ks+1 is read and transformed while the MFMAs
             // of step ks run (needs a second operand set: 16 more VGPRs)
@@ -264,7 +264,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
                 mfma_step(Bs, v);
             }
         }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+        if constexpr (PRIO > 0 && PRIO < 10) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- filters by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no registers) ----
@@ -305,6 +305,10 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
         });
     };
 
+    if constexpr (PRIO >= 10) {
+        // tuner only: de-phase co-resident workgroups (bit (PRIO - 10) of the block index sleeps first)
+        if ((blockIdx.x >> (PRIO - 10)) & 1) __builtin_amdgcn_s_sleep(20);
+    }
     if constexpr (DMA) {
         // two LDS buffers; filters of chunk c+1 stream in by DMA and the input tile of chunk c+1 sits in
         // registers while chunk c is multiplied; ONE barrier per chunk (hipcc drains vmcnt(0) -- i.e. the

@@ -11,128 +11,26 @@
 // Layout: activations are NHWC float32; every tensor slice starts on a 4-channel boundary and is
 // padded to a multiple of 4 channels (padding lanes hold finite values and meet zero weights), so all
 // global traffic is 16-byte vectors.
-#include "conv_wino.hpp"
+#include "conv_variants.hpp"
 
 namespace dcscn {
 
-// ---- variant table ---------------------------------------------------------------------------
-// (mt, kc, wps) as a function of (ks, nt), from tools/conv_tune.hip sweeps on MI355X (1024 48x48
-// patches, gpurun_out/conv_tune*.txt): the single-LDS-buffer form with KC = 4 (3x3) / 16 (1x1) and as
-// many waves per SIMD as the accumulators allow beat the double-buffered form everywhere (CNN2 124 ->
-// 134 TFLOP/s, CNN7 104 -> 121, Up-PS 124 -> 138): extra resident workgroups hide the staging phases
-// better than intra-workgroup double buffering does, and larger KC only cost occupancy.
-__host__ __device__ constexpr int pick_mt(int ks, int nt) {
-    if (ks == 1) return 2;
-    return nt >= 8 ? 2 : (nt >= 5 ? 3 : 4);
-}
-__host__ __device__ constexpr int pick_kc(int ks, int nt) { return ks == 1 ? 16 : 4; }
-__host__ __device__ constexpr int pick_wps(int ks, int nt) {
-    if (nt >= 13) return 2;
-    if (ks == 1) return nt <= 8 ? 4 : 3;
-    return nt >= 7 ? 3 : 4;
-}
-constexpr bool kDoubleBuffer = false;
-
+// ---- dispatch over the per-family translation units (conv_k1.hip, conv_k3.hip, conv_wino.hip) --------
 ConvShape conv_pick_shape(int ks, int nt, int dwk) { return ConvShape{ks, pick_mt(ks, nt), nt, pick_kc(ks, nt), dwk}; }
-
-static size_t lds_bytes_for(int ks, int mt, int nt, int kc) {
-    const int halo = ks / 2;
-    const int hp = (4 * mt + 2 * halo) * (16 + 2 * halo);
-    const int ps = conv_plane_stride(hp);
-    const int ns = conv_ns(nt);
-    return (kDoubleBuffer ? 2 : 1) * (size_t)(kc * ps + ks * ks * kc * ns) * sizeof(float);
-}
 size_t conv_lds_bytes(const ConvShape& s) { return lds_bytes_for(s.ks, s.mt, s.nt, s.kc); }
-
-#define DCSCN_FOR_NT(X, KS) \
-    X(KS, 1) X(KS, 2) X(KS, 3) X(KS, 4) X(KS, 5) X(KS, 6) X(KS, 7) X(KS, 8) X(KS, 9) X(KS, 10) X(KS, 11) X(KS, 12) X(KS, 13)
-
-template <int KS, int NT, int DWK = 0>
-struct Variant {
-    static constexpr int MT = pick_mt(KS, NT), KC = pick_kc(KS, NT), WPS = pick_wps(KS, NT);
-    static constexpr auto kernel = &conv_igemm<KS, MT, NT, KC, kDoubleBuffer, WPS, DWK>;
-    static size_t lds() { return lds_bytes_for(KS, MT, NT, KC); }
-};
-// the fused-depthwise pointwise kernels carry more staging state: keep them at the same occupancy target
-// but only for the channel-tile widths separable models use (<= 8 tiles of 16)
-#define DCSCN_FOR_NT_DW(X, DWK) X(1, 1, DWK) X(1, 2, DWK) X(1, 3, DWK) X(1, 4, DWK) X(1, 5, DWK) X(1, 6, DWK) X(1, 7, DWK) X(1, 8, DWK)
-constexpr int kMaxDwNt = 8;
-
-hipError_t conv_init_kernels() {
-    hipError_t e;
-#define X(KS, NT)                                                                          \
-    {                                                                                      \
-        using V = Variant<KS, NT>;                                                         \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(V::kernel),                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)V::lds()); \
-        if (e != hipSuccess) return e;                                                     \
-    }
-    DCSCN_FOR_NT(X, 1)
-    DCSCN_FOR_NT(X, 3)
-#undef X
-#define X(KS, NT, DWK)                                                                     \
-    {                                                                                      \
-        using V = Variant<KS, NT, DWK>;                                                    \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(V::kernel),                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)V::lds()); \
-        if (e != hipSuccess) return e;                                                     \
-    }
-    DCSCN_FOR_NT_DW(X, 1)
-    DCSCN_FOR_NT_DW(X, 3)
-#undef X
-    return hipSuccess;
-}
-
 int conv_max_fused_dw_nt() { return kMaxDwNt; }
 
-// ---- Winograd variants -----------------------------------------------------------------------
-template <int NT>
-static hipError_t wino_launch_one(const ConvArgs& a, int n_groups, hipStream_t stream) {
-    using G = WinoGeom<NT, kWinoKC>;
-    const size_t lds = (size_t)G::BUF * sizeof(float);
-    const dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)n_groups);
-    // single LDS buffer, 4 waves, filter reads software-pipelined three frequencies ahead (tools/wino_tune.hip)
-    hipLaunchKernelGGL((conv_wino<NT, kWinoKC, 2, false, 0, 4, false, 0, 3>), grid, dim3(256), lds, stream, a);
-    return hipGetLastError();
-}
-
-hipError_t wino_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream) {
-    if (a.nt_last < 1 || a.nt_last > nt) return hipErrorInvalidValue;
-    switch (nt) {
-        case 1: return wino_launch_one<1>(a, n_groups, stream);
-        case 2: return wino_launch_one<2>(a, n_groups, stream);
-        case 3: return wino_launch_one<3>(a, n_groups, stream);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-template <int KS, int NT, int DWK = 0>
-static hipError_t conv_launch_one(const ConvArgs& a, int n_tiles, hipStream_t stream) {
-    using V = Variant<KS, NT, DWK>;
-    const dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)n_tiles);
-    hipLaunchKernelGGL(V::kernel, grid, dim3(256), V::lds(), stream, a);
-    return hipGetLastError();
+hipError_t conv_init_kernels() {
+    hipError_t e = conv_init_k1();
+    return e != hipSuccess ? e : conv_init_k3();
 }
 
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream) {
     if (s.mt != pick_mt(s.ks, s.nt) || s.kc != pick_kc(s.ks, s.nt)) return hipErrorInvalidValue;
-    if (s.dwk != 0) {
-        if (s.ks != 1 || a.dww == nullptr || a.dwk != s.dwk) return hipErrorInvalidValue;
-        switch (s.dwk * 100 + s.nt) {
-#define X(KS, NT, DWK) case DWK * 100 + NT: return conv_launch_one<KS, NT, DWK>(a, n_tiles, stream);
-            DCSCN_FOR_NT_DW(X, 1)
-            DCSCN_FOR_NT_DW(X, 3)
-#undef X
-            default: return hipErrorInvalidValue;
-        }
-    }
-    switch (s.ks * 100 + s.nt) {
-#define X(KS, NT) case KS * 100 + NT: return conv_launch_one<KS, NT>(a, n_tiles, stream);
-        DCSCN_FOR_NT(X, 1)
-        DCSCN_FOR_NT(X, 3)
-#undef X
-        default: return hipErrorInvalidValue;
-    }
+    if (s.dwk != 0 && (s.ks != 1 || a.dww == nullptr || a.dwk != s.dwk)) return hipErrorInvalidValue;
+    if (s.ks == 1) return conv_launch_k1(s.nt, s.dwk, a, n_tiles, stream);
+    if (s.ks == 3) return conv_launch_k3(s.nt, a, n_tiles, stream);
+    return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------

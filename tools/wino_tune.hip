@@ -180,9 +180,10 @@ int main(int argc, char** argv) {
     const Layer cnn8{"CNN8", 97, 86, 1316, 984, 1316, 1084};
     const Layer cnn12{"CNN12", 57, 48, 1316, 1248, 1316, 1268};
     const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
-    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 2>(cnn2);
-    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, -1>(cnn2);
-    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, -2>(cnn2);
     run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);
+    run<2, 11, 3, 4, 2, false, 0, 4, false, 10, 3>(cnn2);
+    run<2, 11, 3, 4, 2, false, 0, 4, false, 18, 3>(cnn2);
+    run<2, 11, 3, 4, 2, false, 0, 4, false, 19, 3>(cnn2);
+    run<2, 11, 3, 4, 2, false, 0, 4, false, 13, 3>(cnn2);
     return 0;
 }
