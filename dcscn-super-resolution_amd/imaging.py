@@ -305,6 +305,38 @@ def compute_psnr_and_ssim(image1, image2, border_size=0):
         image1 = image1[:, :, 0]
         image2 = image2[:, :, 0]
     psnr = _psnr(image1, image2, 255)
-    per_channel = [_ssim_gaussian(image1[..., c], image2[..., c], 255, 1.5, 0.01, 0.03)
-                   for c in range(image1.shape[-1])]
-    return psnr, float(np.mean(per_channel))
+    return psnr, _ssim_last_axis_channels(image1, image2, 255, 1.5, 0.01, 0.03)
+
+
+def _ssim_last_axis_channels(a, b, data_range, sigma, k1, k2):
+    """``structural_similarity(..., multichannel=True)``: the mean over the last axis of the SSIM of each
+    ``a[..., c]``.  For the 2-D arrays the reference passes, every "channel" is one image column, i.e. a 1-D
+    signal filtered along axis 0 -- done for all columns at once (same arithmetic as the per-column loop
+    of ``_ssim_gaussian``; only the order of the final mean's additions differs)."""
+    if a.ndim != 2:
+        return float(np.mean([_ssim_gaussian(a[..., c], b[..., c], data_range, sigma, k1, k2)
+                              for c in range(a.shape[-1])]))
+    from scipy.ndimage import gaussian_filter1d
+    truncate = 3.5
+    radius = int(truncate * sigma + 0.5)
+    win = 2 * radius + 1
+    if a.shape[0] < win:
+        raise ValueError("win_size exceeds image extent")
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    cov_norm = win / (win - 1.0)             # NP = win ** ndim with ndim = 1 per column
+
+    def f(x):
+        return gaussian_filter1d(x, sigma, axis=0, truncate=truncate)
+
+    ux, uy = f(a), f(b)
+    uxx, uyy, uxy = f(a * a), f(b * b), f(a * b)
+    vx = cov_norm * (uxx - ux * ux)
+    vy = cov_norm * (uyy - uy * uy)
+    vxy = cov_norm * (uxy - ux * uy)
+    c1 = (k1 * data_range) ** 2
+    c2 = (k2 * data_range) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+    pad = (win - 1) // 2
+    per_column = s[pad:a.shape[0] - pad, :].mean(axis=0, dtype=np.float64)
+    return float(per_column.mean(dtype=np.float64))

@@ -157,6 +157,20 @@ def test_imaging_helpers():
     assert util.compute_psnr_and_ssim(a, b[:-1]) is None
 
 
+def test_ssim_vectorised_equals_per_column_loop():
+    """The reference's SSIM quirk (columns as channels, utilty.py:529-535): the vectorised evaluation
+    must equal the literal per-column loop."""
+    from dcscn_amd import imaging as util
+    rng = np.random.default_rng(3)
+    a = rng.uniform(0, 255, (37, 23)).round()
+    b = np.clip(a + rng.normal(0, 9, a.shape), 0, 255).round()
+    fast = util._ssim_last_axis_channels(a, b, 255, 1.5, 0.01, 0.03)
+    loop = float(np.mean([util._ssim_gaussian(a[:, c], b[:, c], 255, 1.5, 0.01, 0.03) for c in range(a.shape[1])]))
+    assert abs(fast - loop) < 1e-14
+    with pytest.raises(ValueError):
+        util._ssim_last_axis_channels(a[:10], b[:10], 255, 1.5, 0.01, 0.03)
+
+
 def test_bicubic_goldens_through_the_host_glue(oracle):
     """evaluate_bicubic's recipe with the package's own helpers reproduces the oracle's numbers."""
     from dcscn_amd import imaging as util
