@@ -646,8 +646,9 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     // The Winograd kernel's cost follows its number of channel groups (ceil(tiles / 3)), not its MFMA
     // count: with 4 tiles of 16 (3 + 1) the direct kernel wins (CNN11 66->57: 1.37 vs 1.49 ms), and a
     // single tile gains nothing.
-    if (h->winograd && op.ks == 3 && op.dwk == 0 && op.cin_phys >= 32 && op.segs.size() == 1 && tiles16 >= 2 &&
-        tiles16 != 4) {
+    // (op.vec4: the Winograd epilogue only has the 16-byte store form)
+    if (h->winograd && op.vec4 && op.ks == 3 && op.dwk == 0 && op.cin_phys >= 32 && op.segs.size() == 1 &&
+        tiles16 >= 2 && tiles16 != 4) {
         const int nt = std::min(kWinoMaxNT, tiles16);
         op.shape = ConvShape{3, 4, nt, kWinoKC, 0, 1};
         op.n_tiles = (tiles16 + nt - 1) / nt;

@@ -253,69 +253,110 @@ __global__ __launch_bounds__(256, WPS) void conv_igemm(const ConvArgs a) {
     }
 
     // ---- epilogue: bias, activator, (depth_to_space), (residual), store ----
+    // Runs once per workgroup, but its instruction count matters against a ~4 k-cycle chunk: activator
+    // and store form are launch constants and dispatched ONCE (not per stored value), the destination
+    // index math is done once per channel tile, rows differ by a constant stride.
     const int gx = x0 + lj;
     const int gy0 = y0 + wave * MT;
-    const int cbase = ntile * NT * 16;
+    const int cbase = ntile * NT * 16 + 4 * lk;
     const int act = a.act;
     if (gx >= W) return;
-    static_for<0, NT>([&](auto n_) DCSCN_INL {
-        constexpr int n = decltype(n_)::value;
-        const int c = cbase + n * 16 + 4 * lk;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c);
-        f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (act == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(a.alpha + c);
-        const bool first = c < a.split;
-        float* optr = first ? a.out0.ptr : a.out1.ptr;
-        const int ostride = first ? a.out0.stride : a.out1.stride;
-        const int ooff = first ? a.out0.off : a.out1.off;
-        const int owidth = first ? a.out0.width : a.out1.width;
-        const int cc = first ? c : c - a.split;
-        // destination of channel cc+r: pixel (gy*ps + ay[r], gx*ps + bx[r]), channel ch[r]
-        int ch[4], ay[4], bx[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ccr = cc + r;
-            if (a.ps == 1) {
-                ch[r] = ccr; ay[r] = 0; bx[r] = 0;
-            } else {
-                const int sub = ccr / a.ps_c;
-                ch[r] = ccr - sub * a.ps_c;
-                ay[r] = sub / a.ps;
-                bx[r] = sub - ay[r] * a.ps;
+    const int ps = a.ps;
+    const int orow = W * ps;                                   // destination pixels per row
+    auto finish = [&](auto act_c, auto vec_c) DCSCN_INL {
+        constexpr int ACT_C = decltype(act_c)::value;
+        constexpr bool VEC = decltype(vec_c)::value;
+        const int act_e = ACT_C >= 0 ? ACT_C : act;
+        f32x4 bv_next = *reinterpret_cast<const f32x4*>(a.bias + cbase);
+        f32x4 av_next = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (act_e == ACT_ALPHA) av_next = *reinterpret_cast<const f32x4*>(a.alpha + cbase);
+        static_for<0, NT>([&](auto n_) DCSCN_INL {
+            constexpr int n = decltype(n_)::value;
+            const int c = cbase + n * 16;
+            const f32x4 bv = bv_next, av = av_next;
+            if constexpr (n + 1 < NT) {                        // next tile's bias / slope while this one is stored
+                bv_next = *reinterpret_cast<const f32x4*>(a.bias + c + 16);
+                if (act_e == ACT_ALPHA) av_next = *reinterpret_cast<const f32x4*>(a.alpha + c + 16);
             }
-        }
-        const size_t orow = (size_t)W * a.ps;
-        static_for<0, MT>([&](auto m_) DCSCN_INL {
-            constexpr int m = decltype(m_)::value;
-            const int gy = gy0 + m;
-            if (gy < H) {
-                f32x4 v = acc[m][n] + bv;
-                v.x = activate1(v.x, av.x, act);
-                v.y = activate1(v.y, av.y, act);
-                v.z = activate1(v.z, av.z, act);
-                v.w = activate1(v.w, av.w, act);
-                const size_t prow = ((size_t)img * H + gy) * a.ps;
-                if (a.vec4) {
-                    if (cc < owidth) {
-                        const size_t pix = (prow + ay[0]) * orow + (size_t)gx * a.ps + bx[0];
-                        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + pix * a.res_stride + ch[0]);
-                        *reinterpret_cast<f32x4*>(optr + pix * ostride + ooff + ch[0]) = v;
+            const bool first = c < a.split;
+            float* optr = first ? a.out0.ptr : a.out1.ptr;
+            const int ostride = first ? a.out0.stride : a.out1.stride;
+            const int ooff = first ? a.out0.off : a.out1.off;
+            const int owidth = first ? a.out0.width : a.out1.width;
+            const int cc = first ? c : c - a.split;
+            const size_t dy = (size_t)ps * orow * ostride;     // one LR row down in the destination
+            if constexpr (VEC) {
+                // the 4 channels of this lane stay together: pixel (gy*ps + ay, gx*ps + bx), channels ch..ch+3
+                int ch = cc, ay = 0, bx = 0;
+                if (ps != 1) {
+                    const int sub = cc / a.ps_c;
+                    ch = cc - sub * a.ps_c;
+                    ay = sub / ps;
+                    bx = sub - ay * ps;
+                }
+                const size_t pix0 = (size_t)((img * H + gy0) * ps + ay) * orow + (size_t)(gx * ps + bx);
+                float* o0 = optr + pix0 * ostride + ooff + ch;
+                const bool live = cc < owidth;
+                static_for<0, MT>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    f32x4 v = acc[m][n] + bv;
+                    v.x = activate1(v.x, av.x, act_e);
+                    v.y = activate1(v.y, av.y, act_e);
+                    v.z = activate1(v.z, av.z, act_e);
+                    v.w = activate1(v.w, av.w, act_e);
+                    if (live && gy0 + m < H) {
+                        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + (pix0 + (size_t)(m * ps) * orow) * a.res_stride + ch);
+                        *reinterpret_cast<f32x4*>(o0 + m * dy) = v;
                     }
-                } else {
-                    const float vr[4] = {v.x, v.y, v.z, v.w};
+                });
+            } else {
+                // scalar stores: ragged widths / offsets, or depth_to_space splitting the 4 channels
+                size_t pix0[4];
+                int ch[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (cc + r < owidth) {
-                            const size_t pix = (prow + ay[r]) * orow + (size_t)gx * a.ps + bx[r];
-                            float out = vr[r];
-                            if (a.res) out += a.res[pix * a.res_stride + ch[r]];
-                            optr[pix * ostride + ooff + ch[r]] = out;
+                for (int r = 0; r < 4; ++r) {
+                    const int ccr = cc + r;
+                    int ay = 0, bx = 0;
+                    ch[r] = ccr;
+                    if (ps != 1) {
+                        const int sub = ccr / a.ps_c;
+                        ch[r] = ccr - sub * a.ps_c;
+                        ay = sub / ps;
+                        bx = sub - ay * ps;
+                    }
+                    pix0[r] = (size_t)((img * H + gy0) * ps + ay) * orow + (size_t)(gx * ps + bx);
+                }
+                static_for<0, MT>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    f32x4 v = acc[m][n] + bv;
+                    v.x = activate1(v.x, av.x, act_e);
+                    v.y = activate1(v.y, av.y, act_e);
+                    v.z = activate1(v.z, av.z, act_e);
+                    v.w = activate1(v.w, av.w, act_e);
+                    if (gy0 + m < H) {
+                        const float vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (cc + r < owidth) {
+                                const size_t pix = pix0[r] + (size_t)(m * ps) * orow;
+                                float out = vr[r];
+                                if (a.res) out += a.res[pix * a.res_stride + ch[r]];
+                                optr[pix * ostride + ooff + ch[r]] = out;
+                            }
                         }
                     }
-                }
+                });
             }
         });
-    });
+    };
+    using std::integral_constant;
+    if (a.vec4) {
+        if (act == ACT_ALPHA) finish(integral_constant<int, ACT_ALPHA>{}, integral_constant<bool, true>{});
+        else if (act == ACT_NONE) finish(integral_constant<int, ACT_NONE>{}, integral_constant<bool, true>{});
+        else finish(integral_constant<int, -1>{}, integral_constant<bool, true>{});
+    } else {
+        finish(integral_constant<int, -1>{}, integral_constant<bool, false>{});
+    }
 }
 
 

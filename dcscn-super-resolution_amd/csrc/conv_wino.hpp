@@ -105,9 +105,12 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
         static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
             const int c = c0 + a_c4[i];
-            areg[i] = *reinterpret_cast<const f32x4*>(a_src[i] + (c < c_last ? c : c_last));
+            if constexpr (ABLATE == 9 || ABLATE == 11)   // tuner only: same bytes, fully coalesced (wrong data)
+                areg[i] = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(blockIdx.x & 1023) * 49 + chunk) * 2048 + 4 * (tid + THREADS * i));
+            else
+                areg[i] = *reinterpret_cast<const f32x4*>(a_src[i] + (c < c_last ? c : c_last));
         });
-        const float* bs = b_src + (size_t)chunk * G::B_FLOATS;
+        const float* bs = b_src + ((ABLATE == 10 || ABLATE == 11) ? 0 : (size_t)chunk * G::B_FLOATS);   // 10/11: tuner only
         static_for<0, G::B_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
             breg[i] = *reinterpret_cast<const f32x4*>(bs + 4 * THREADS * i);
@@ -373,7 +376,44 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
             if (more) store_chunk(nxt, chunk + 1);
             __syncthreads();
         }
-    } else {
+    } else if constexpr (ABLATE == 7) {
+        // tuner only: s_memtime stamps at the phase boundaries of the shipped loop; per-wave cycle sums
+        // of the four phases go to the debug buffer passed in `a.alpha` (16 longs per wave)
+        long long t_store = 0, t_bar1 = 0, t_comp = 0, t_bar2 = 0;
+        const long long c_begin = __builtin_readcyclecounter();
+        const long long r_begin = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        load_chunk(0);
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            const long long t0 = __builtin_readcyclecounter();
+            store_chunk(smem, chunk);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long long t1 = __builtin_readcyclecounter();
+            __syncthreads();
+            const long long t2 = __builtin_readcyclecounter();
+            if (chunk + 1 < a.n_chunks) load_chunk(chunk + 1);
+            compute(smem);
+            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[15][NTV - 1]));
+            const long long t3 = __builtin_readcyclecounter();
+            __syncthreads();
+            const long long t4 = __builtin_readcyclecounter();
+            t_store += t1 - t0; t_bar1 += t2 - t1; t_comp += t3 - t2; t_bar2 += t4 - t3;
+        }
+        if (lane == 0 && blockIdx.x < 4096) {
+            long long* dbg = reinterpret_cast<long long*>(const_cast<float*>(a.alpha)) + ((size_t)blockIdx.x * 4 + wave) * 4 + 1024;
+            dbg[0] = t_store; dbg[1] = t_bar1; dbg[2] = t_comp; dbg[3] = t_bar2;
+            if (wave == 0 && blockIdx.x < 512) {   // shader-clock calibration: s_memtime vs s_memrealtime
+                long long* cal = reinterpret_cast<long long*>(const_cast<float*>(a.alpha)) + blockIdx.x * 2;
+                cal[0] = __builtin_readcyclecounter() - c_begin;
+                cal[1] = __builtin_amdgcn_s_memrealtime() - r_begin;
+            }
+        }
+        if (tid == 0) {
+            long long* life = reinterpret_cast<long long*>(const_cast<float*>(a.alpha)) + 1024 + 4096 * 16 +
+                              ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+            life[4] = c_begin; life[5] = __builtin_readcyclecounter();
+        }
+    } else if constexpr (ABLATE == 8) {
+        // tuner only: the pre-r01 order (loads issued after the first barrier)
         load_chunk(0);
         for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
             store_chunk(smem, chunk);
@@ -382,39 +422,65 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
             compute(smem);
             __syncthreads();
         }
+    } else {
+        // The loop is bound by the latency of the chunk loads (s_memtime stamps: ~17 % of a chunk is the
+        // vmcnt wait in front of the LDS store), so the loads of chunk c+1 are issued as early as their
+        // registers are free -- right after the LDS writes of chunk c, before the barrier.
+        load_chunk(0);
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            store_chunk(smem, chunk);
+            if (chunk + 1 < a.n_chunks) load_chunk(chunk + 1);
+            __syncthreads();
+            compute(smem);
+            __syncthreads();
+        }
     }
 
     // ---- output transform (wave-local) + epilogue ----
+    // Runs once per workgroup but is not free: the first version (per-position 64-bit index math, a
+    // scalar-store fallback) cost ~21 k cycles against ~4 k per chunk. Now: vec4 stores only (the host
+    // routes anything else to conv_igemm), every load issued up front, one 64-bit multiply per channel
+    // tile and constant strides between the four positions of a lane's 2x2 output block.
     const int gy0 = y0 + 2 * tr;
     const int gx0 = x0 + 2 * tc;
-    const int cbase = ntile * NT * 16;
+    const int cbase = ntile * NT * 16 + 4 * lk;
     const int act = a.act;
+    const int ps = a.ps;
+    const int orow = W * ps;                                   // destination pixels per row
+    const bool ok_y1 = gy0 + 1 < H, ok_x1 = gx0 + 1 < W;
+    const bool ok_00 = gy0 < H && gx0 < W;
+    f32x4 bv[NTV], av[NTV];
     static_for<0, NTV>([&](auto n_) DCSCN_INL {
         constexpr int n = decltype(n_)::value;
-        const int c = cbase + n * 16 + 4 * lk;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c);
-        f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (act == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(a.alpha + c);
+        bv[n] = *reinterpret_cast<const f32x4*>(a.bias + cbase + n * 16);
+        av[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (act == ACT_ALPHA) av[n] = *reinterpret_cast<const f32x4*>(a.alpha + cbase + n * 16);
+    });
+    // the activator is a launch constant: dispatch once, not once per stored value
+    auto finish = [&](auto act_c) DCSCN_INL {
+    constexpr int ACT_C = decltype(act_c)::value;
+    const int act_e = ACT_C >= 0 ? ACT_C : act;
+    static_for<0, NTV>([&](auto n_) DCSCN_INL {
+        constexpr int n = decltype(n_)::value;
+        const int c = cbase + n * 16;
         const bool first = c < a.split;
         float* optr = first ? a.out0.ptr : a.out1.ptr;
         const int ostride = first ? a.out0.stride : a.out1.stride;
         const int ooff = first ? a.out0.off : a.out1.off;
         const int owidth = first ? a.out0.width : a.out1.width;
         const int cc = first ? c : c - a.split;
-        int ch[4], ay[4], bx[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ccr = cc + r;
-            if (a.ps == 1) {
-                ch[r] = ccr; ay[r] = 0; bx[r] = 0;
-            } else {
-                const int sub = ccr / a.ps_c;
-                ch[r] = ccr - sub * a.ps_c;
-                ay[r] = sub / a.ps;
-                bx[r] = sub - ay[r] * a.ps;
-            }
+        int ch = cc, ay = 0, bx = 0;
+        if (ps != 1) {                                         // depth_to_space: channel (ay*ps + bx)*ps_c + ch
+            const int sub = cc / a.ps_c;
+            ch = cc - sub * a.ps_c;
+            ay = sub / ps;
+            bx = sub - ay * ps;
         }
-        const size_t orow = (size_t)W * a.ps;
+        const size_t pix00 = (size_t)((img * H + gy0) * ps + ay) * orow + (size_t)(gx0 * ps + bx);
+        float* o00 = optr + pix00 * ostride + ooff + ch;
+        const size_t dx = (size_t)ps * ostride;                // one LR pixel to the right / down
+        const size_t dy = (size_t)ps * orow * ostride;
+        const bool live = ok_00 && cc < owidth;
         // t[a][nu] = sum_xi A^T[a][xi] m[xi][nu],  A^T = [1 1 1 0; 0 1 -1 -1]
         f32x4 t0[4], t1[4];
         static_for<0, 4>([&](auto nu_) DCSCN_INL {
@@ -430,36 +496,25 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
         static_for<0, 2>([&](auto pa_) DCSCN_INL {
             static_for<0, 2>([&](auto pb_) DCSCN_INL {
                 constexpr int pa = decltype(pa_)::value, pb = decltype(pb_)::value;
-                const int gy = gy0 + pa, gx = gx0 + pb;
-                if (gy < H && gx < W) {
-                    f32x4 v = yv[pa][pb] + bv;
-                    v.x = activate1(v.x, av.x, act);
-                    v.y = activate1(v.y, av.y, act);
-                    v.z = activate1(v.z, av.z, act);
-                    v.w = activate1(v.w, av.w, act);
-                    const size_t prow = ((size_t)img * H + gy) * a.ps;
-                    if (a.vec4) {
-                        if (cc < owidth) {
-                            const size_t pix = (prow + ay[0]) * orow + (size_t)gx * a.ps + bx[0];
-                            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + pix * a.res_stride + ch[0]);
-                            *reinterpret_cast<f32x4*>(optr + pix * ostride + ooff + ch[0]) = v;
-                        }
-                    } else {
-                        const float vr[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (cc + r < owidth) {
-                                const size_t pix = (prow + ay[r]) * orow + (size_t)gx * a.ps + bx[r];
-                                float out = vr[r];
-                                if (a.res) out += a.res[pix * a.res_stride + ch[r]];
-                                optr[pix * ostride + ooff + ch[r]] = out;
-                            }
-                        }
+                f32x4 v = yv[pa][pb] + bv[n];
+                v.x = activate1(v.x, av[n].x, act_e);
+                v.y = activate1(v.y, av[n].y, act_e);
+                v.z = activate1(v.z, av[n].z, act_e);
+                v.w = activate1(v.w, av[n].w, act_e);
+                if (live && (pa == 0 || ok_y1) && (pb == 0 || ok_x1)) {
+                    if (a.res) {
+                        const size_t pix = pix00 + (size_t)(pa * ps) * orow + (size_t)(pb * ps);
+                        v += *reinterpret_cast<const f32x4*>(a.res + pix * a.res_stride + ch);
                     }
+                    *reinterpret_cast<f32x4*>(o00 + pa * dy + pb * dx) = v;
                 }
             });
         });
     });
+    };
+    if (act == ACT_ALPHA) finish(std::integral_constant<int, ACT_ALPHA>{});
+    else if (act == ACT_NONE) finish(std::integral_constant<int, ACT_NONE>{});
+    else finish(std::integral_constant<int, -1>{});
 }
 
 // WAVES waves per workgroup = a (4*WAVES) x 16 output-pixel tile; launch_bounds' second argument is
@@ -468,6 +523,21 @@ template <int NT, int KC, int WPS, bool DB = false, int ABLATE = 0, int WAVES = 
 __global__ __launch_bounds__(64 * WAVES, WPS) void conv_wino(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nt_valid = (blockIdx.y == gridDim.y - 1) ? a.nt_last : NT;   // block uniform
+    if constexpr (ABLATE == 7) {
+        // tuner only: workgroup lifetime in shader cycles and 100 MHz ticks (wave 0)
+        const long long c0 = __builtin_readcyclecounter();
+        const long long r0 = __builtin_amdgcn_s_memrealtime();
+        conv_wino_body<NT, NT, KC, DB, ABLATE, WAVES, DMA, PRIO, PF, VPIPE>(a, smem);
+        const long long c1 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            long long* life = reinterpret_cast<long long*>(const_cast<float*>(a.alpha)) + 1024 + 4096 * 16 +
+                              ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+            life[0] = r0; life[1] = __builtin_amdgcn_s_memrealtime(); life[2] = c0; life[3] = __builtin_readcyclecounter();
+            life[6] = c1;
+        }
+        return;
+    }
     if (nt_valid == NT) conv_wino_body<NT, NT, KC, DB, ABLATE, WAVES, DMA, PRIO, PF, VPIPE>(a, smem);
     else if constexpr (NT >= 2) {
         if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC, DB, ABLATE, WAVES, DMA, PRIO, PF, VPIPE>(a, smem);
