@@ -655,7 +655,7 @@ int finalize_op(dcscn_ctx* h, Op& op) {
         op.nt_last = tiles16 - (op.n_tiles - 1) * nt;
         op.ctot = op.n_tiles * nt * 16;
         op.n_chunks = (op.cin_phys + kWinoKC - 1) / kWinoKC;
-        const int ns = conv_ns(nt), kc = kWinoKC;
+        const int ns = wino_glb_ns(nt), kc = kWinoKC;
         const size_t chunk_floats = (size_t)16 * kc * ns;
         // + one staging sweep of slack: the kernel loads the last partial sweep of a chunk with every
         // thread (only the LDS store is predicated), which may run past the final chunk by < 2048 floats
@@ -679,7 +679,7 @@ int finalize_op(dcscn_ctx* h, Op& op) {
                 for (int xi = 0; xi < 4; ++xi)
                     for (int nu = 0; nu < 4; ++nu) {                // (G g) G^T, float64, rounded once
                         const double u = gg[xi][0] * G[nu][0] + gg[xi][1] * G[nu][1] + gg[xi][2] * G[nu][2];
-                        pack[((size_t)tile * op.n_chunks + chunk) * chunk_floats + ((size_t)(xi * 4 + nu) * kc + kk) * ns + jn] = (float)u;
+                        pack[((size_t)tile * op.n_chunks + chunk) * chunk_floats + ((size_t)(xi * 4 + nu) * kc + kk) * ns + wino_glb_col(nt, jn)] = (float)u;
                     }
             }
         }

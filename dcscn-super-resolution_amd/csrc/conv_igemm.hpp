@@ -8,6 +8,7 @@
 namespace dcscn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
 
 // ---------------------------------------------------------------------------------------------
 // activator (helper/tf_graph.py:77-102)

@@ -34,14 +34,19 @@ struct WinoGeom {
     static constexpr int HTH = TH + 2, HTW = TW + 2;
     static constexpr int HP = HTH * HTW;
     static constexpr int PS = conv_plane_stride(HP);
-    static constexpr int NS = conv_ns(NT);
+    static constexpr int NS = wino_lds_ns(NT);        // floats per (f, kk) filter row in LDS
+    static constexpr int GNS = wino_glb_ns(NT);       // ... in the global image
+    static constexpr int NPAD = wino_npad(NT);
+    static constexpr bool SCATTER = NS != GNS;        // NT = 3: 12-byte items padded to 16 on the way into LDS
     static constexpr int KQ = KC / 4;
     static constexpr int A_FLOATS = KC * PS;
     static constexpr int B_FLOATS = 16 * KC * NS;
     static constexpr int BUF = A_FLOATS + B_FLOATS;
     static constexpr int A_ITEMS = HP * KQ;
     static constexpr int A_LOADS = (A_ITEMS + THREADS - 1) / THREADS;
-    static constexpr int B_VEC = B_FLOATS / 4;
+    static constexpr int GB_FLOATS = 16 * KC * GNS;   // one chunk of one group in global memory
+    // staging items: float4 of the linear image, or (SCATTER) one (f, kk, j) triple
+    static constexpr int B_VEC = SCATTER ? 16 * KC * 16 : GB_FLOATS / 4;
     static constexpr int B_LOADS = (B_VEC + THREADS - 1) / THREADS;
 };
 
@@ -92,15 +97,16 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
         // unconditionally and masked when written to LDS, so no branch sits between a load and its use
         a_src[i] = in_img + ((size_t)(a_inb[i] ? gy : 0) * W + (a_inb[i] ? gx : 0)) * a.in_stride;
     });
-    const float* b_src = a.wpack + (size_t)ntile * a.n_chunks * G::B_FLOATS + 4 * tid;
+    const float* b_src = a.wpack + (size_t)ntile * a.n_chunks * G::GB_FLOATS + (G::SCATTER ? 3 : 4) * tid;
     const int c_last = a.cin_phys - 4;
 
     f32x4 areg[G::A_LOADS];
-    f32x4 breg[G::B_LOADS];
+    using bvec_t = std::conditional_t<G::SCATTER, f32x3, f32x4>;
+    bvec_t breg[G::B_LOADS];
 
     // NOTE: the filter buffer is over-allocated by one staging sweep, so the last (partial) sweep of a
     // chunk may be loaded by every thread; only its LDS store is predicated.
-    auto load_chunk = [&](int chunk) DCSCN_INL {
+    auto load_a = [&](int chunk) DCSCN_INL {
         const int c0 = chunk * KC;
         static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
@@ -110,31 +116,51 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
             else
                 areg[i] = *reinterpret_cast<const f32x4*>(a_src[i] + (c < c_last ? c : c_last));
         });
-        const float* bs = b_src + ((ABLATE == 10 || ABLATE == 11) ? 0 : (size_t)chunk * G::B_FLOATS);   // 10/11: tuner only
+    };
+    auto load_b = [&](int chunk) DCSCN_INL {
+        const float* bs = b_src + ((ABLATE == 10 || ABLATE == 11) ? 0 : (size_t)chunk * G::GB_FLOATS);   // 10/11: tuner only
         static_for<0, G::B_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
-            breg[i] = *reinterpret_cast<const f32x4*>(bs + 4 * THREADS * i);
+            if constexpr (G::SCATTER) {
+                const float* q = bs + 3 * THREADS * i;           // 12-byte items: 4-byte aligned only
+                breg[i] = f32x3{q[0], q[1], q[2]};
+            } else {
+                breg[i] = *reinterpret_cast<const f32x4*>(bs + 4 * THREADS * i);
+            }
         });
     };
-    auto store_chunk = [&](float* buf, int chunk) DCSCN_INL {
+    auto load_chunk = [&](int chunk) DCSCN_INL {
+        load_a(chunk);
+        load_b(chunk);
+    };
+    auto store_a = [&](float* buf, int chunk) DCSCN_INL {
         const int c0 = chunk * KC;
         static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
             if (a_item[i]) {
-                const bool keep = a_inb[i] && c0 + a_c4[i] < a.cin_phys;
+                // zero padding (halo outside the image, channels past cin) by bit mask: exact for any
+                // loaded bit pattern and, unlike `keep ? v : 0`, never compiled into branches
+                const bool keep = a_inb[i] && (G::KQ == 1 || c0 + a_c4[i] < a.cin_phys);
+                const unsigned m = keep ? 0xffffffffu : 0u;
                 float* d = buf + a_dst[i];
-                d[0] = keep ? areg[i].x : 0.0f;
-                d[G::PS] = keep ? areg[i].y : 0.0f;
-                d[2 * G::PS] = keep ? areg[i].z : 0.0f;
-                d[3 * G::PS] = keep ? areg[i].w : 0.0f;
+                d[0] = __uint_as_float(__float_as_uint(areg[i].x) & m);
+                d[G::PS] = __uint_as_float(__float_as_uint(areg[i].y) & m);
+                d[2 * G::PS] = __uint_as_float(__float_as_uint(areg[i].z) & m);
+                d[3 * G::PS] = __uint_as_float(__float_as_uint(areg[i].w) & m);
             }
         });
+    };
+    auto store_b = [&](float* buf) DCSCN_INL {
         float* bd = buf + G::A_FLOATS + 4 * tid;
         static_for<0, G::B_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
             if (i < G::B_LOADS - 1 || tid + THREADS * i < G::B_VEC)
-                *reinterpret_cast<f32x4*>(bd + 4 * THREADS * i) = breg[i];
+                *reinterpret_cast<bvec_t*>(bd + 4 * THREADS * i) = breg[i];   // SCATTER: 12 of each 16 bytes
         });
+    };
+    auto store_chunk = [&](float* buf, int chunk) DCSCN_INL {
+        store_a(buf, chunk);
+        store_b(buf);
     };
 
     f32x4 acc[16][NTV];
@@ -148,7 +174,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     const int tr = 2 * wave + (lj >> 3);
     const int tc = lj & 7;
     const int a_lane = lk * G::PS + (2 * tr) * G::HTW + 2 * tc;   // raw 4x4 patch origin in the halo tile
-    const int b_lane = G::A_FLOATS + lk * G::NS + lj;
+    const int b_lane = G::A_FLOATS + lk * G::NS + (kWinoBVec ? lj * G::NPAD : lj);
 
     // raw 4x4 patch of this lane's (tile, channel) for k-step `ks` -> transformed operands v[16]
     auto read_raw = [&](const float* As, float (&d)[4][4]) DCSCN_INL {
@@ -179,55 +205,74 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     };
     // the 16*NTV MFMAs of one k-step; filter operands read PF frequencies ahead (PF = 0: hipcc's order,
     // which keeps a single operand pair in flight and stalls on every frequency)
-    auto mfma_step = [&](const float* Bs, const float (&v)[16]) DCSCN_INL {
+    // filter operands of frequency f for this lane's NTV channel tiles
+    auto read_w = [&](const float* Bs, int f, float (&w)[NTV]) DCSCN_INL {
+        const float* q = Bs + (f * KC) * G::NS;
+        if constexpr (!kWinoBVec) {
+            static_for<0, NTV>([&](auto n_) DCSCN_INL { w[decltype(n_)::value] = q[decltype(n_)::value * 16]; });
+        } else if constexpr (NTV == 1) {
+            w[0] = q[0];
+        } else if constexpr (NTV == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(q);
+            w[0] = t.x; w[1] = t.y;
+        } else {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(q);   // b128 (4 LDS cycles) rather than b96 (8); the pad lane is dead
+            w[0] = t.x; w[1] = t.y; w[2] = t.z;
+        }
+    };
+    constexpr int W_READS = kWinoBVec ? 1 : NTV;   // DS instructions per read_w
+    constexpr int kHookF = 3;                      // frequency after which the pipelined loop stages the next chunk
+    auto mfma_step = [&](const float* Bs, const float (&v)[16], auto&& hook) DCSCN_INL {
         if constexpr (PF < 0) {
             // tuner only: let LLVM's IGroupLP strategy (-PF - 1) interleave DS reads and MFMAs
             __builtin_amdgcn_iglp_opt(-PF - 1);
             static_for<0, 16>([&](auto f_) DCSCN_INL {
                 constexpr int f = decltype(f_)::value;
+                float w[NTV];
+                read_w(Bs, f, w);
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
                     constexpr int n = decltype(n_)::value;
-                    const float wv = Bs[(f * KC) * G::NS + n * 16];
-                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[f], acc[f][n], 0, 0, 0);
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n], v[f], acc[f][n], 0, 0, 0);
                 });
             });
         } else if constexpr (PF == 0) {
             static_for<0, 16>([&](auto f_) DCSCN_INL {
                 constexpr int f = decltype(f_)::value;
+                float w[NTV];
+                if constexpr (ABLATE == 6) {   // tuner only: no filter reads
+                    static_for<0, NTV>([&](auto n_) DCSCN_INL { w[decltype(n_)::value] = breg[0].x; });
+                } else {
+                    read_w(Bs, f, w);
+                }
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
                     constexpr int n = decltype(n_)::value;
-                    const float wv = ABLATE == 6 ? breg[0].x : Bs[(f * KC) * G::NS + n * 16];   // 6: tuner only
-                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[f], acc[f][n], 0, 0, 0);
+                    acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[n], v[f], acc[f][n], 0, 0, 0);
                 });
             });
         } else {
             float wq[(PF > 0 ? PF : 0) + 1][NTV];
             static_for<0, PF>([&](auto p_) DCSCN_INL {
                 constexpr int pf = decltype(p_)::value;
-                static_for<0, NTV>([&](auto n_) DCSCN_INL {
-                    constexpr int n = decltype(n_)::value;
-                    wq[pf][n] = Bs[(pf * KC) * G::NS + n * 16];
-                });
+                read_w(Bs, pf, wq[pf]);
             });
             static_for<0, 16>([&](auto f_) DCSCN_INL {
                 constexpr int f = decltype(f_)::value;
                 if constexpr (f + PF < 16) {
-                    static_for<0, NTV>([&](auto n_) DCSCN_INL {
-                        constexpr int n = decltype(n_)::value;
-                        wq[(f + PF) % (PF + 1)][n] = Bs[((f + PF) * KC) * G::NS + n * 16];
-                    });
-                    __builtin_amdgcn_sched_group_barrier(0x100, NTV, 0);   // DS reads of f + PF
+                    read_w(Bs, f + PF, wq[(f + PF) % (PF + 1)]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, W_READS, 0);   // DS reads of f + PF
                 }
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
                     constexpr int n = decltype(n_)::value;
                     acc[f][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[f % (PF + 1)][n], v[f], acc[f][n], 0, 0, 0);
                 });
                 __builtin_amdgcn_sched_group_barrier(0x8, NTV, 0);          // MFMAs of f
+                hook(f_);                                                   // pipelined loops hang work on chosen frequencies
             });
         }
     };
 
-    auto compute = [&](const float* buf) DCSCN_INL {
+    auto no_hook = [](auto) DCSCN_INL {};
+    auto compute_h = [&](const float* buf, auto&& hook) DCSCN_INL {
         const float* As = buf + a_lane;
         const float* Bs = buf + b_lane;
         if constexpr (PRIO > 0 && PRIO < 10) __builtin_amdgcn_s_setprio(PRIO);
@@ -244,8 +289,8 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
                 constexpr int ks = decltype(ks_)::value;
                 float d[4][4];
                 if constexpr (ks + 1 < G::KQ) read_raw(As + (ks + 1) * 4 * G::PS, d);
-                if constexpr (ks % 2 == 0) mfma_step(Bs + ks * 4 * G::NS, va);
-                else mfma_step(Bs + ks * 4 * G::NS, vb);
+                if constexpr (ks % 2 == 0) mfma_step(Bs + ks * 4 * G::NS, va, no_hook);
+                else mfma_step(Bs + ks * 4 * G::NS, vb, no_hook);
                 if constexpr (ks + 1 < G::KQ) {
                     if constexpr (ks % 2 == 0) transform(d, vb);
                     else transform(d, va);
@@ -264,16 +309,19 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
                     read_raw(As, d);
                     transform(d, v);
                 }
-                mfma_step(Bs, v);
+                if constexpr (G::KQ == 1) mfma_step(Bs, v, hook);   // the hook exists for one-step chunks only
+                else mfma_step(Bs, v, no_hook);
             }
         }
         if constexpr (PRIO > 0 && PRIO < 10) __builtin_amdgcn_s_setprio(0);
     };
+    auto compute = [&](const float* buf) DCSCN_INL { compute_h(buf, no_hook); };
 
     // ---- filters by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no registers) ----
     auto dma_filters = [&](int chunk, float* buf) DCSCN_INL {
         constexpr int PIECES = G::B_FLOATS / 256;
-        static_assert(G::B_FLOATS % 256 == 0, "filter block must be whole 1 KB DMA pieces");
+        static_assert(!DMA || G::B_FLOATS % 256 == 0, "filter block must be whole 1 KB DMA pieces");
+        static_assert(!DMA || !G::SCATTER, "the DMA experiment copies the filter image linearly");
         const float* src = a.wpack + ((size_t)ntile * a.n_chunks + chunk) * G::B_FLOATS + 4 * lane;
         float* dst = buf + G::A_FLOATS;
         static_for<0, (PIECES + WAVES - 1) / WAVES>([&](auto i_) DCSCN_INL {
@@ -298,12 +346,15 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
         static_for<0, G::A_LOADS>([&](auto i_) DCSCN_INL {
             constexpr int i = decltype(i_)::value;
             if (a_item[i]) {
-                const bool keep = a_inb[i] && c0 + a_c4[i] < a.cin_phys;
+                // zero padding (halo outside the image, channels past cin) by bit mask: exact for any
+                // loaded bit pattern and, unlike `keep ? v : 0`, never compiled into branches
+                const bool keep = a_inb[i] && (G::KQ == 1 || c0 + a_c4[i] < a.cin_phys);
+                const unsigned m = keep ? 0xffffffffu : 0u;
                 float* d = buf + a_dst[i];
-                d[0] = keep ? areg[i].x : 0.0f;
-                d[G::PS] = keep ? areg[i].y : 0.0f;
-                d[2 * G::PS] = keep ? areg[i].z : 0.0f;
-                d[3 * G::PS] = keep ? areg[i].w : 0.0f;
+                d[0] = __uint_as_float(__float_as_uint(areg[i].x) & m);
+                d[G::PS] = __uint_as_float(__float_as_uint(areg[i].y) & m);
+                d[2 * G::PS] = __uint_as_float(__float_as_uint(areg[i].z) & m);
+                d[3 * G::PS] = __uint_as_float(__float_as_uint(areg[i].w) & m);
             }
         });
     };
@@ -337,7 +388,11 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
         load_chunk(0);
         store_chunk(smem, 0);
         __syncthreads();
-        for (int chunk = 0; chunk < a.n_chunks; ++chunk) compute(smem);
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            float* b = smem;
+            asm volatile("" : "+v"(b));     // opaque per iteration: the LDS reads cannot be hoisted
+            compute(b);
+        }
     } else if constexpr (ABLATE == 3) {
         // tuner only: barriers kept, no staging
         load_chunk(0);
@@ -363,17 +418,72 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
             compute(smem);
             __syncthreads();
         }
+    } else if constexpr (DB && VPIPE) {
+        // Fully software-pipelined loop: two [input | filter] LDS buffers, ONE barrier per chunk, and every
+        // non-MFMA job of a chunk hidden behind the MFMAs of the previous one IN THE SAME WAVE:
+        //   after frequency 3 : registers -> LDS (filters of chunk c+1, input tile of chunk c+2), then the
+        //                       global loads of filters c+2 / input c+3
+        //   after frequency 7 : raw 4x4 patch of chunk c+1 LDS -> registers (v[0..7] of chunk c are dead)
+        //   after frequency 11: its input transform (32 adds), interleaved with the last MFMAs
+        // Chunk indices are clamped instead of branched on, so the loop body is one basic block; the few
+        // redundant loads / stores of the last two iterations land in dead buffers.
+        static_assert(G::KQ == 1 && PF > 0, "pipelined loop: one MFMA step per chunk, prefetched filter operands");
+        const int last = a.n_chunks - 1;
+        auto clamp = [&](int c) DCSCN_INL { return c < last ? c : last; };
+        float v[16];
+        load_chunk(0);
+        store_chunk(smem, 0);                 // input 0, filters 0 -> buffer 0
+        load_a(clamp(1));
+        store_a(smem + G::BUF, clamp(1));     // input 1 -> buffer 1
+        load_b(clamp(1));
+        load_a(clamp(2));
+        __syncthreads();
+        {
+            float d[4][4];
+            read_raw(smem + a_lane, d);
+            transform(d, v);
+        }
+        for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
+            float* cur = smem + (chunk & 1) * G::BUF;
+            float* nxt = smem + ((chunk + 1) & 1) * G::BUF;
+            float dn[4][4], vn[16];
+            mfma_step(cur + b_lane, v, [&](auto f_) DCSCN_INL {
+                constexpr int F = decltype(f_)::value;
+                if constexpr (F == 3) {
+                    store_b(nxt);                          // filters c+1
+                    store_a(cur, clamp(chunk + 2));        // input c+2 over input c (read during chunk c-1)
+                    load_b(clamp(chunk + 2));
+                    load_a(clamp(chunk + 3));
+                } else if constexpr (F == 7) {
+                    read_raw(nxt + a_lane, dn);
+                } else if constexpr (F == 11) {
+                    transform(dn, vn);
+                }
+            });
+            __syncthreads();
+            static_for<0, 16>([&](auto f_) DCSCN_INL { v[decltype(f_)::value] = vn[decltype(f_)::value]; });
+        }
     } else if constexpr (DB) {
+        // Software-pipelined loop over two LDS buffers, ONE barrier per chunk: while the MFMAs of chunk c
+        // run, the same wave writes chunk c+1 (in registers since the middle of the previous chunk) into
+        // the other buffer and issues the global loads of chunk c+2 -- staging sits in the MFMA shadow
+        // instead of between two barriers.
+        static_assert(G::KQ == 1 && PF > 0, "pipelined loop: one MFMA step per chunk, prefetched filter operands");
         load_chunk(0);
         store_chunk(smem, 0);
+        if (a.n_chunks > 1) load_chunk(1);
         __syncthreads();
         for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
             float* cur = smem + (chunk & 1) * G::BUF;
             float* nxt = smem + ((chunk + 1) & 1) * G::BUF;
-            const bool more = chunk + 1 < a.n_chunks;
-            if (more) load_chunk(chunk + 1);
-            compute(cur);
-            if (more) store_chunk(nxt, chunk + 1);
+            compute_h(cur, [&](auto f_) DCSCN_INL {
+                if constexpr (decltype(f_)::value == kHookF) {
+                    if (chunk + 1 < a.n_chunks) {
+                        store_chunk(nxt, chunk + 1);
+                        if (chunk + 2 < a.n_chunks) load_chunk(chunk + 2);
+                    }
+                }
+            });
             __syncthreads();
         }
     } else if constexpr (ABLATE == 7) {

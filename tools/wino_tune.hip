@@ -47,13 +47,13 @@ static std::vector<float> pack_direct(const std::vector<float>& w, int cin, int 
 
 // winograd pack: [ntile][chunk][f][kk][NS], U = G g G^T in double
 static std::vector<float> pack_wino(const std::vector<float>& w, int cin, int cout, int cin_phys, int kc, int nt, int* n_chunks, int* n_tiles, int* nt_last) {
-    const int ns = conv_ns(nt);
+    const int ns = wino_glb_ns(nt);
     const int tiles16 = (cout + 15) / 16;
     *n_tiles = (tiles16 + nt - 1) / nt;
     *nt_last = tiles16 - (*n_tiles - 1) * nt;
     *n_chunks = (cin_phys + kc - 1) / kc;
     const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    std::vector<float> p((size_t)*n_tiles * *n_chunks * 16 * kc * ns, 0.0f);
+    std::vector<float> p((size_t)*n_tiles * *n_chunks * 16 * kc * ns + 2048, 0.0f);
     for (int c = 0; c < cin; ++c)
         for (int o = 0; o < cout; ++o) {
             double g[3][3];
@@ -66,7 +66,7 @@ static std::vector<float> pack_wino(const std::vector<float>& w, int cin, int co
                     for (int i = 0; i < 3; ++i)
                         for (int j = 0; j < 3; ++j) u += G[xi][i] * g[i][j] * G[nu][j];
                     const int f = xi * 4 + nu;
-                    p[(((size_t)tile * *n_chunks + c / kc) * 16 + f) * kc * ns + (size_t)(c % kc) * ns + jn] = (float)u;
+                    p[(((size_t)tile * *n_chunks + c / kc) * 16 + f) * kc * ns + (size_t)(c % kc) * ns + wino_glb_col(nt, jn)] = (float)u;
                 }
         }
     return p;
@@ -186,6 +186,20 @@ void run(const Layer& L) {
                 const double span = (double)(tmax - tmin);
                 printf("   %d workgroups: device span %.3f ms, mean lifetime %.1f us = %.0f cycles (%.0f MHz), slot occupancy %.1f%% of 512\n",
                        nwg, span / 1e5, occ_ticks / nwg / 100.0, cyc / nwg, cyc / occ_ticks * 100.0, occ_ticks / (span * 512.0) * 100.0);
+                {
+                    printf("   chunk-loop cycles by dispatch-order decile:");
+                    const int tot = nwg;
+                    for (int dcl = 0; dcl < 10; ++dcl) {
+                        double sm = 0; int cn = 0;
+                        for (int g = dcl * tot / 10; g < (dcl + 1) * tot / 10; ++g) {
+                            const long long* e = life + 8 * (size_t)g;
+                            if (e[1] == 0) continue;
+                            sm += (double)(e[5] - e[4]); ++cn;
+                        }
+                        printf(" %.0f", cn ? sm / cn : 0.0);
+                    }
+                    printf("\n");
+                }
                 printf("   wave 0 cycles: prologue %.0f  chunk loop %.0f  output transform + store issue %.0f  store drain %.0f\n",
                        pro / nwg, loop / nwg, epi / nwg, drain / nwg);
             }
@@ -225,6 +239,8 @@ int main(int argc, char** argv) {
     const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
     run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);
     run<2, 11, 3, 4, 2, false, 7, 4, false, 0, 3>(cnn2);
-    run<2, 8, 3, 4, 2, false, 7, 4, false, 0, 3>(cnn5);
+    run<2, 11, 3, 4, 2, true, 0, 4, false, 0, 3>(cnn2);
+    run<2, 11, 2, 4, 2, true, 0, 4, false, 0, 3, true>(cnn2);
+    run<2, 8, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn5);
     return 0;
 }
