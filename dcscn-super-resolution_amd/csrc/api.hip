@@ -83,6 +83,9 @@ struct Op {
     float out_scale = 1.0f;         // OP_COUT1: pointwise scalar of a separable 1->1 conv
     int tconv_s = 0;                // > 0: the op is tf.nn.conv2d_transpose with this stride, run as its
                                     // equivalent 3x3 conv to s*s*C channels + depth_to_space (see add_tconv)
+    int fold_s = 0;                 // > 0: folded linear tail (see fold_linear_tail): pixel-shuffler block
+    int fold_c = 0;                 //      channels after depth_to_space
+    int fold_rw = -1;               //      filter tensor of the last reconstruction conv [3, 3, C, 1]
     // output
     int out_buf[2] = {EXT_Y, EXT_Y}, out_off[2] = {0, 0}, out_width[2] = {0, 0};
     int split = 1 << 30;
@@ -134,6 +137,7 @@ struct dcscn_ctx {
     int64_t workspace_budget = (int64_t)48 << 30;
     bool profile = false;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
+    bool fold_tail = false;                  // opt-in graph rewrite, see fold_linear_tail()
     std::vector<hipEvent_t> ev;              // event pool: 2 per launch
     size_t ev_used = 0;                      // events recorded since the last dcscn_get_profile
     int ev_forwards = 0;                     // forwards recorded since the last dcscn_get_profile
@@ -570,6 +574,63 @@ int build_graph(dcscn_ctx* h) {
     return DCSCN_OK;
 }
 
+// ---- optional graph rewrite: the linear tail as one conv ----------------------------------------
+//
+// The last pixel-shuffler stage (3x3 conv + bias, NO activator, DCSCN.py:293-311), depth_to_space and the
+// last reconstruction conv (3x3 to 1 channel, no bias, no activator, DCSCN.py:319-323) are all linear, so
+// their composition is ONE convolution of the low-resolution map: HR pixel (s y + a, s x + b) is a 5x5
+// conv of the LR neighbourhood of (y, x) with a kernel that depends on the sub-pixel phase (a, b) only:
+//
+//   out(sy+a, sx+b) = sum_{dy,dx} sum_c Wr[dy][dx][c] U_c(sy+a+dy, sx+b+dx),   U_c(Y, X) = UpConv(Y div s, X div s)[((Y mod s) s + X mod s) C + c]
+//
+// except that the reconstruction conv zero-pads the HR map: a tap that leaves the image is dropped, which
+// changes the composite kernel (and its bias term) on the border rows / columns of that phase.  Per phase
+// only one row tap (dy = -1 for a = 0, dy = +1 for a = s-1) and one column tap can leave, so 4 "border
+// variants" per phase cover every case; the launch computes all of them (conv channel = phase * 4 +
+// variant; the 16-wide MFMA channel tile is padded anyway) and the epilogue keeps the one that applies.
+// 25 * Cin * 4 s^2 MACs per LR pixel replace 9 * Cin * s^2 C + 9 s^2 C (C = 96, s = 2: 38 k instead of 335 k),
+// and the s^2 C-channel HR map is never written.  The result equals the layer-by-layer graph in exact
+// arithmetic; in f32 it differs by re-association (composite weights are formed in float64 and rounded
+// once).  Opt-in (option "fold_linear_tail"), because it no longer executes the reference's layers one by one.
+bool fold_linear_tail(dcscn_ctx* h) {
+    const dcscn_config& c = h->cfg;
+    if (!c.pixel_shuffler || c.depthwise_separable || c.cnn_size != 3 || c.reconstruct_layers > 1) return false;
+    if (h->ops.size() < 2) return false;
+    const Op r = h->ops[h->ops.size() - 1];
+    const Op u = h->ops[h->ops.size() - 2];
+    if (u.kind != OP_CONV || u.ps < 2 || u.ps > 4 || u.segs.size() != 1 || u.dwk != 0 || u.tconv_s != 0 || u.act != ACT_NONE) return false;
+    const bool r_ok = (r.kind == OP_COUT1 && r.dw_w < 0) || (r.kind == OP_CONV && r.cout == 1 && r.dwk == 0);
+    if (!r_ok || !r.residual || r.segs.size() != 1 || r.segs[0].b >= 0 || r.act != ACT_NONE || r.ks != 3) return false;
+    if (r.in_buf != u.out_buf[0] || r.cin != u.ps_c || (u.ps * u.ps + 3) / 4 > 4) return false;
+    Op f = u;
+    f.name = u.name + "+" + r.name + " (folded)";
+    f.ks = 5;
+    f.cout = 4 * u.ps * u.ps;
+    f.segs[0].cout = f.cout;
+    f.segs[0].dst = 0;
+    f.fold_s = u.ps;
+    f.fold_c = u.ps_c;
+    f.fold_rw = r.segs[0].w;
+    f.out_buf[0] = f.out_buf[1] = EXT_Y;
+    f.out_off[0] = f.out_off[1] = 0;
+    f.out_width[0] = 1;
+    f.out_width[1] = 0;
+    f.split = 1 << 30;
+    f.residual = true;
+    f.vec4 = false;
+    f.macs = u.macs + r.macs;                       // algorithmic work of the layers it replaces
+    const int64_t hr2 = (int64_t)u.res * u.ps * u.res * u.ps;
+    f.bytes = 4 * (int64_t)u.res * u.res * u.cin_phys + 8 * hr2;
+    const int dead = u.out_buf[0];
+    h->ops.pop_back();
+    h->ops.pop_back();
+    bool used = false;
+    for (const Op& o : h->ops) used = used || o.in_buf == dead || o.out_buf[0] == dead || o.out_buf[1] == dead;
+    if (!used && dead >= 0) h->bufs[dead].stride = 0;   // the shuffled HR map no longer exists
+    h->ops.push_back(f);
+    return true;
+}
+
 // ---- weight repack -----------------------------------------------------------------------------
 
 int upload(dcscn_ctx* h, const void* host, size_t bytes, void** dev) {
@@ -634,7 +695,47 @@ int finalize_op(dcscn_ctx* h, Op& op) {
                                     t.data[(((size_t)ky * kk + kx) * C + oc) * C + ic];
                     }
     }
-    const TensorSpec* w_override = op.tconv_s > 0 ? &derived : nullptr;
+    // folded linear tail: composite 5x5 filter [5][5][cin][phase * 4 + variant] and its bias, in float64
+    std::vector<float> derived_bias;
+    if (op.fold_s > 0) {
+        const int sc = op.fold_s, C = op.fold_c, cin = (int)op.chan_map.size(), V = 4 * sc * sc, UC = sc * sc * C;
+        const TensorSpec& wu = h->tensors[op.segs[0].w];     // [3, 3, cin, s*s*C]
+        const TensorSpec& wr = h->tensors[op.fold_rw];       // [3, 3, C, 1]
+        const float* bu = op.segs[0].b >= 0 ? h->tensors[op.segs[0].b].data.data() : nullptr;
+        std::vector<double> wacc((size_t)25 * cin * V, 0.0), bacc(V, 0.0);
+        auto fdiv = [](int x, int d) { return x >= 0 ? x / d : -((-x + d - 1) / d); };
+        for (int pa = 0; pa < sc; ++pa)
+            for (int pb = 0; pb < sc; ++pb)
+                for (int var = 0; var < 4; ++var) {
+                    const int v = (pa * sc + pb) * 4 + var;
+                    const bool rbit = var & 2, cbit = var & 1;
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        if (rbit && ((pa == 0 && dy == -1) || (pa == sc - 1 && dy == 1))) continue;   // tap above / below the image
+                        const int oy = fdiv(pa + dy, sc), a2 = pa + dy - oy * sc;
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (cbit && ((pb == 0 && dx == -1) || (pb == sc - 1 && dx == 1))) continue;
+                            const int ox = fdiv(pb + dx, sc), b2 = pb + dx - ox * sc;
+                            for (int cc = 0; cc < C; ++cc) {
+                                const double wrv = wr.data[((size_t)(dy + 1) * 3 + (dx + 1)) * C + cc];
+                                const int ch = (a2 * sc + b2) * C + cc;
+                                if (bu) bacc[v] += wrv * bu[ch];
+                                for (int ey = -1; ey <= 1; ++ey)
+                                    for (int ex = -1; ex <= 1; ++ex) {
+                                        const size_t tap5 = (size_t)(oy + ey + 2) * 5 + (ox + ex + 2);
+                                        const float* wsrc = &wu.data[((size_t)(ey + 1) * 3 + (ex + 1)) * cin * UC + ch];
+                                        double* wdst = &wacc[tap5 * cin * V + v];
+                                        for (int k = 0; k < cin; ++k) wdst[(size_t)k * V] += wrv * wsrc[(size_t)k * UC];
+                                    }
+                            }
+                        }
+                    }
+                }
+        derived.data.resize(wacc.size());
+        for (size_t i = 0; i < wacc.size(); ++i) derived.data[i] = (float)wacc[i];
+        derived_bias.resize(V);
+        for (int v = 0; v < V; ++v) derived_bias[v] = (float)bacc[v];
+    }
+    const TensorSpec* w_override = (op.tconv_s > 0 || op.fold_s > 0) ? &derived : nullptr;
 
     // OP_CONV: dense [tap][k_phys][conv channel] -> [n_tile][chunk][tap][kk][NS]
     int ctot = 0;
@@ -727,7 +828,8 @@ int finalize_op(dcscn_ctx* h, Op& op) {
                 }
             }
         for (int co = 0; co < s.cout; ++co) {
-            if (s.b >= 0) bias[s.dst + co] = h->tensors[s.b].data[co];
+            if (op.fold_s > 0) bias[s.dst + co] = derived_bias[co];
+            else if (s.b >= 0) bias[s.dst + co] = h->tensors[s.b].data[co];
             alpha[s.dst + co] = s.alpha >= 0 ? h->tensors[s.alpha].data[co] : op.const_alpha;
         }
     }
@@ -849,6 +951,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     a.res_stride = 1;
     a.dww = op.d_dww;
     a.dwk = op.dwk;
+    a.fold = op.fold_s > 0 ? 1 : 0;
     if (op.shape.wino) HIP_TRY(h, wino_launch(op.shape.nt, a, op.n_tiles, stream));
     else HIP_TRY(h, conv_launch(op.shape, a, op.n_tiles, stream));
     return DCSCN_OK;
@@ -1046,6 +1149,7 @@ int dcscn_finalize(dcscn_handle h) {
     for (const TensorSpec& t : h->tensors)
         if (!t.set) return fail(h, DCSCN_ERR_MISSING_TENSOR, "variable '%s' was never set", t.name.c_str());
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->fold_tail) fold_linear_tail(h);      // silently keeps the layer-by-layer graph where it does not apply
     for (Op& op : h->ops) {
         int rc = finalize_op(h, op);
         if (rc) return rc;
@@ -1107,6 +1211,11 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "workspace_budget_bytes")) {
         if (value < 1) return fail(h, DCSCN_ERR_INVALID_ARG, "workspace_budget_bytes must be >= 1");
         h->workspace_budget = value;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "fold_linear_tail")) {
+        if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the fold_linear_tail option must be set before dcscn_finalize");
+        h->fold_tail = value != 0;
         return DCSCN_OK;
     }
     if (!strcmp(key, "winograd")) {

@@ -264,6 +264,37 @@ __global__ __launch_bounds__(256, WPS) void conv_igemm(const ConvArgs a) {
     if (gx >= W) return;
     const int ps = a.ps;
     const int orow = W * ps;                                   // destination pixels per row
+    if constexpr (KS == 5) {
+        if (a.fold) {
+            // Folded linear tail: conv channel n*16 + 4*lk + r is (phase n*4 + lk, border variant r).
+            // Variant bit 1 = this phase's out-of-image HR row tap is dropped (phase row 0 at the top image
+            // row, phase row ps-1 at the bottom one), bit 0 the same for columns.
+            float* yout = a.out0.ptr;
+            static_for<0, NT>([&](auto n_) DCSCN_INL {
+                constexpr int n = decltype(n_)::value;
+                const int phase = n * 4 + lk;
+                if (phase < ps * ps) {
+                    const int pa = phase / ps, pb = phase - pa * ps;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n * 16 + 4 * lk);
+                    const bool cb = (pb == 0 && gx == 0) || (pb == ps - 1 && gx == W - 1);
+                    static_for<0, MT>([&](auto m_) DCSCN_INL {
+                        constexpr int m = decltype(m_)::value;
+                        const int gy = gy0 + m;
+                        if (gy < H) {
+                            const bool rb = (pa == 0 && gy == 0) || (pa == ps - 1 && gy == H - 1);
+                            const f32x4 v = acc[m][n] + bv;
+                            const float lo = cb ? v.y : v.x, hi = cb ? v.w : v.z;
+                            const size_t idx = ((size_t)(img * H + gy) * ps + pa) * orow + (size_t)(gx * ps + pb);
+                            float out = rb ? hi : lo;
+                            if (a.res) out += a.res[idx];
+                            yout[idx] = out;
+                        }
+                    });
+                }
+            });
+            return;
+        }
+    }
     auto finish = [&](auto act_c, auto vec_c) DCSCN_INL {
         constexpr int ACT_C = decltype(act_c)::value;
         constexpr bool VEC = decltype(vec_c)::value;

@@ -57,5 +57,10 @@ hipError_t conv_init_k1();
 hipError_t conv_init_k3();
 hipError_t conv_launch_k1(int nt, int dwk, const ConvArgs& a, int n_tiles, hipStream_t stream);
 hipError_t conv_launch_k3(int nt, const ConvArgs& a, int n_tiles, hipStream_t stream);
+// 5x5: only the channel-tile counts the folded linear tail needs (ceil(s*s / 4) for pixel-shuffler block s <= 4)
+#define DCSCN_FOR_NT_K5(X) X(5, 1) X(5, 2) X(5, 3) X(5, 4)
+constexpr int kMaxK5Nt = 4;
+hipError_t conv_init_k5();
+hipError_t conv_launch_k5(int nt, const ConvArgs& a, int n_tiles, hipStream_t stream);
 
 }  // namespace dcscn

@@ -42,6 +42,11 @@ struct ConvArgs {
     const float* dww;         // [dwk*dwk][cin_phys], physical channel order, zero padded (or nullptr)
     int32_t dwk;              // depthwise kernel size: 0 (none), 1 or 3
     int32_t nt_last;          // conv_wino: 16-channel tiles that are real in the last channel group
+    // Folded linear tail (5x5 kernels): the launch computes, for every LR pixel, `ps*ps` sub-pixel phases
+    // x 4 border variants of the composite [pixel-shuffler conv -> depth_to_space -> 3x3 conv to 1 channel];
+    // conv channel v = phase * 4 + variant.  The epilogue picks the variant of each phase from the pixel's
+    // position and stores one value per HR pixel into out0 (stride 1), plus `res`.
+    int32_t fold;
 };
 
 struct ConvShape {            // kernel variant picked by the plan

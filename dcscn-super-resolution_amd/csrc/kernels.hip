@@ -22,7 +22,8 @@ int conv_max_fused_dw_nt() { return kMaxDwNt; }
 
 hipError_t conv_init_kernels() {
     hipError_t e = conv_init_k1();
-    return e != hipSuccess ? e : conv_init_k3();
+    if (e == hipSuccess) e = conv_init_k3();
+    return e != hipSuccess ? e : conv_init_k5();
 }
 
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream) {
@@ -30,6 +31,7 @@ hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipSt
     if (s.dwk != 0 && (s.ks != 1 || a.dww == nullptr || a.dwk != s.dwk)) return hipErrorInvalidValue;
     if (s.ks == 1) return conv_launch_k1(s.nt, s.dwk, a, n_tiles, stream);
     if (s.ks == 3) return conv_launch_k3(s.nt, a, n_tiles, stream);
+    if (s.ks == 5 && s.nt <= kMaxK5Nt) return conv_launch_k5(s.nt, a, n_tiles, stream);
     return hipErrorInvalidValue;
 }
 

@@ -259,11 +259,18 @@ class Engine:
         self._check(self._lib.dcscn_set_tensor(self._h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                                                shape, a.ndim))
 
-    def load_weights(self, tensors, winograd=None):
+    def load_weights(self, tensors, winograd=None, fold_tail=None):
         """Feed every variable the graph needs from ``{name: ndarray}`` and finalize.
-        ``winograd=False`` keeps every 3x3 conv on the direct implicit-GEMM kernel (default: library choice)."""
+        ``winograd=False`` keeps every 3x3 conv on the direct implicit-GEMM kernel (default: library choice).
+        ``fold_tail=True`` opts into running the linear tail (last pixel-shuffler conv, depth_to_space, last
+        reconstruction conv) as one 5x5 conv -- see "fold_linear_tail" in include/dcscn.h; the default
+        (also settable with the environment variable DCSCN_FOLD_TAIL=1) executes the reference's layers one by one."""
         if winograd is not None:
             self.set_option("winograd", 1 if winograd else 0)
+        if fold_tail is None and os.environ.get("DCSCN_FOLD_TAIL") == "1":
+            fold_tail = True
+        if fold_tail is not None:
+            self.set_option("fold_linear_tail", 1 if fold_tail else 0)
         for name, _ in self.tensor_specs():
             if name not in tensors:
                 raise EngineError(3, "variable '%s' is missing from the checkpoint" % name)

@@ -185,3 +185,77 @@ def test_full_size_bench_workload(oracle):
     pick = [0, 1, 511, 512, 1000, 1023]
     ref = oracle.forward(cfg, weights, x[pick], x2[pick], dtype=np.float64)
     assert float(np.max(np.abs(y[pick] - ref))) <= MAX_ABS_TOL
+
+
+# ---- opt-in graph rewrite: the linear tail as one 5x5 conv (include/dcscn.h "fold_linear_tail") ----------
+
+def _fold_engine(cfg, weights, fold=True):
+    from dcscn_amd import engine
+    eng = engine.Engine(cfg, device=0)
+    eng.load_weights(weights, fold_tail=fold)
+    return eng
+
+
+def _folded(eng):
+    return [op["name"] for op in eng.ops() if "(folded)" in op["name"]]
+
+
+@pytest.mark.parametrize("name", ["L2_F4to4_x2", "L8_F96to48_x2", "L12_F196to48_x2", "L12_F196to48_x4",
+                                  "L7_F32to8_x2", "L7_F32to8_x3", "L7_F32to8_x4"])
+def test_folded_tail_configs(oracle, name):
+    """Pixel-shuffler conv + depth_to_space + R-CNN as ONE conv: same 1e-4 bar against the float64 oracle of
+    the layer-by-layer graph; the rewrite must actually have happened (one launch named '... (folded)')."""
+    cfg = oracle.make_config(**CONFIGS[name])
+    weights = oracle.synthetic_weights(cfg, seed=11)
+    n = 2
+    x, x2 = synthetic_batch(n, 48, 48, cfg["scale"], seed=12)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with _fold_engine(cfg, weights) as eng:
+        assert len(_folded(eng)) == 1, eng.ops()
+        y = eng.forward(x, x2)
+    err = float(np.max(np.abs(y.astype(np.float64) - ref)))
+    print("%s folded tail: max-abs err %.3g" % (name, err))
+    assert err <= MAX_ABS_TOL
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4])
+@pytest.mark.parametrize("hw", [(1, 1), (1, 6), (7, 1), (2, 2), (3, 5), (16, 16), (17, 33)])
+def test_folded_tail_borders(oracle, scale, hw):
+    """The composite kernel changes on the border rows / columns of each sub-pixel phase (the reconstruction conv
+    zero-pads the HR map).  Bare network branch (x2 = 0, last conv not scaled down) so that a wrong border
+    variant cannot hide behind the bicubic term; images down to one pixel, where every pixel is a border."""
+    cfg = oracle.make_config(layers=3, filters=16, min_filters=8, scale=scale, pixel_shuffler_filters=5)
+    weights = oracle.synthetic_weights(cfg, seed=20 + scale)
+    weights["R-CNN1/conv_W"] = weights["R-CNN1/conv_W"] * 100.0
+    x, _ = synthetic_batch(2, hw[0], hw[1], scale, seed=30)
+    x2 = np.zeros((2, hw[0] * scale, hw[1] * scale, 1), np.float32)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with _fold_engine(cfg, weights) as eng:
+        assert len(_folded(eng)) == 1
+        y = eng.forward(x, x2)
+    with _fold_engine(cfg, weights, fold=False) as eng:
+        assert not _folded(eng)
+        y0 = eng.forward(x, x2)
+    mag = float(np.max(np.abs(ref)))
+    rel = float(np.max(np.abs(y - ref))) / mag
+    rel0 = float(np.max(np.abs(y0 - ref))) / mag
+    print("x%d %dx%d folded rel err %.3g (layer by layer %.3g, max|y| %.3g)" % (scale, hw[0], hw[1], rel, rel0, mag))
+    assert rel <= 1e-5
+
+
+@pytest.mark.parametrize("variant", [
+    dict(layers=3, filters=16, min_filters=8, depthwise_separable=True),                 # separable convs
+    dict(layers=3, filters=16, min_filters=8, pixel_shuffler=False),                     # transposed-conv upsampler
+    dict(layers=3, filters=24, min_filters=8, reconstruct_layers=3, reconstruct_filters=12),   # activators in the tail
+    dict(layers=2, filters=8, min_filters=8, cnn_size=1),
+])
+def test_folded_tail_not_applicable(oracle, variant):
+    """Where the tail is not [PS conv, depth_to_space, one 3x3 conv] the option is ignored, not an error."""
+    cfg = oracle.make_config(**variant)
+    weights = oracle.synthetic_weights(cfg, seed=5)
+    x, x2 = synthetic_batch(1, 12, 20, cfg["scale"], seed=6)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with _fold_engine(cfg, weights) as eng:
+        assert not _folded(eng)
+        y = eng.forward(x, x2)
+    assert float(np.max(np.abs(y - ref))) <= MAX_ABS_TOL
