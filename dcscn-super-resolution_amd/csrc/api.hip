@@ -129,6 +129,9 @@ struct dcscn_ctx {
     // host-path staging
     float* io_x = nullptr; float* io_x2 = nullptr; float* io_y = nullptr;
     size_t io_x_cap = 0, io_y_cap = 0;
+    // spatial tiling of images larger than one pass (run_tiled): gathered tile batch
+    float* tile_x = nullptr; float* tile_x2 = nullptr; float* tile_y = nullptr;
+    size_t tile_x_cap = 0, tile_y_cap = 0;
     std::vector<void*> device_allocs;
 
     // LR pixels per pass through the layer chain.  Big passes keep >= ~10 rounds of workgroups per
@@ -138,6 +141,7 @@ struct dcscn_ctx {
     bool profile = false;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
     bool fold_tail = false;                  // opt-in graph rewrite, see fold_linear_tail()
+    bool spatial_tiling = true;              // images larger than one pass are cut into haloed windows (run_tiled)
     std::vector<hipEvent_t> ev;              // event pool: 2 per launch
     size_t ev_used = 0;                      // events recorded since the last dcscn_get_profile
     int ev_forwards = 0;                     // forwards recorded since the last dcscn_get_profile
@@ -957,6 +961,97 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     return DCSCN_OK;
 }
 
+// Receptive-field radius of y_ in LR pixels: every launch widens it by floor(k/2) pixels of ITS resolution.
+// (Summing over all launches over-counts the parallel A1 / B1->B2 branches by nothing: 1x1 convs add 0.)
+int halo_lr_pixels(const dcscn_ctx* h) {
+    double r = 0.0;
+    for (const Op& op : h->ops) {
+        const int k = op.kind == OP_CONV && op.dwk ? op.dwk : op.ks;
+        r += (double)(k / 2) / op.res;
+    }
+    return (int)std::ceil(r - 1e-9);
+}
+
+int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, int H, int W, hipStream_t stream);
+
+// An image that does not fit one pass of the layer chain (workspace budget / sub_batch_pixels) is cut into
+// equally shaped windows that overlap by twice the receptive-field radius R; the windows run as an ordinary
+// batch and every output pixel is taken from a window in which it lies >= R pixels away from any window edge
+// that is not also an image edge.  There the value is the same function of the same inputs as in the untiled
+// pass (SAME zero padding only ever acts at true image borders), so no per-layer masking is needed.
+int run_tiled(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, int H, int W, int64_t pass_pixels,
+              hipStream_t stream) {
+    const int R = halo_lr_pixels(h), s = h->cfg.scale;
+    // window shape: as square as the pass allows, never wider / taller than the image
+    int Ht = (int)std::min<int64_t>(H, std::max<int64_t>(1, (int64_t)std::sqrt((double)pass_pixels)));
+    int Wt = (int)std::min<int64_t>(W, std::max<int64_t>(1, pass_pixels / Ht));
+    if (Wt == W) Ht = (int)std::min<int64_t>(H, pass_pixels / Wt);
+    if ((Ht < H && Ht <= 2 * R) || (Wt < W && Wt <= 2 * R))
+        return fail(h, DCSCN_ERR_NOMEM, "image %dx%d needs spatial tiling, but a pass of %lld LR pixels is too small for windows "
+                    "with a %d-pixel halo; raise sub_batch_pixels / workspace_budget_bytes", H, W, (long long)pass_pixels, R);
+    auto starts = [&](int full, int win) {
+        std::vector<int> v;
+        if (win >= full) { v.push_back(0); return v; }
+        const int stride = win - 2 * R;
+        for (int a = 0; a + win < full; a += stride) v.push_back(a);
+        v.push_back(full - win);
+        return v;
+    };
+    const std::vector<int> ys = starts(H, Ht), xs = starts(W, Wt);
+    const size_t tiles = (size_t)n * ys.size() * xs.size();
+    const size_t lr = tiles * Ht * Wt, hr = lr * s * s;
+    if (lr > h->tile_x_cap || hr > h->tile_y_cap) {
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        for (float** p : {&h->tile_x, &h->tile_x2, &h->tile_y}) {
+            if (*p) HIP_TRY(h, hipFree(*p));
+            *p = nullptr;
+        }
+        h->tile_x_cap = h->tile_y_cap = 0;
+        HIP_TRY(h, hipMalloc((void**)&h->tile_x, lr * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->tile_x2, hr * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void**)&h->tile_y, hr * sizeof(float)));
+        h->tile_x_cap = lr;
+        h->tile_y_cap = hr;
+    }
+    size_t t = 0;
+    for (int img = 0; img < n; ++img)
+        for (int wy : ys)
+            for (int wx : xs) {
+                HIP_TRY(h, hipMemcpy2DAsync(h->tile_x + t * Ht * Wt, (size_t)Wt * sizeof(float),
+                                            x + ((size_t)img * H + wy) * W + wx, (size_t)W * sizeof(float),
+                                            (size_t)Wt * sizeof(float), Ht, hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(h, hipMemcpy2DAsync(h->tile_x2 + t * Ht * Wt * s * s, (size_t)Wt * s * sizeof(float),
+                                            x2 + ((size_t)img * H * s + (size_t)wy * s) * W * s + (size_t)wx * s, (size_t)W * s * sizeof(float),
+                                            (size_t)Wt * s * sizeof(float), (size_t)Ht * s, hipMemcpyDeviceToDevice, stream));
+                ++t;
+            }
+    int rc = run_forward(h, h->tile_x, h->tile_x2, h->tile_y, (int)tiles, Ht, Wt, stream);
+    if (rc) return rc;
+    // scatter: window i owns [a_i + (a_i > 0 ? R : 0), a_{i+1} + R) -- up to the next window's first owned pixel
+    auto owned = [&](const std::vector<int>& st, size_t i, int full, int win, int* lo, int* hi) {
+        *lo = st[i] + (st[i] > 0 ? R : 0);
+        *hi = i + 1 < st.size() ? st[i + 1] + R : full;
+        (void)win;
+    };
+    t = 0;
+    for (int img = 0; img < n; ++img)
+        for (size_t iy = 0; iy < ys.size(); ++iy)
+            for (size_t ix = 0; ix < xs.size(); ++ix) {
+                int y0, y1, x0, x1;
+                owned(ys, iy, H, Ht, &y0, &y1);
+                owned(xs, ix, W, Wt, &x0, &x1);
+                if (y1 > y0 && x1 > x0) {
+                    const float* src = h->tile_y + t * Ht * Wt * s * s + ((size_t)(y0 - ys[iy]) * s) * Wt * s + (size_t)(x0 - xs[ix]) * s;
+                    float* dst = y + ((size_t)img * H * s + (size_t)y0 * s) * W * s + (size_t)x0 * s;
+                    HIP_TRY(h, hipMemcpy2DAsync(dst, (size_t)W * s * sizeof(float), src, (size_t)Wt * s * sizeof(float),
+                                                (size_t)(x1 - x0) * s * sizeof(float), (size_t)(y1 - y0) * s,
+                                                hipMemcpyDeviceToDevice, stream));
+                }
+                ++t;
+            }
+    return DCSCN_OK;
+}
+
 int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, int H, int W, hipStream_t stream) {
     if (!h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_forward before dcscn_finalize");
     if (n < 0 || H <= 0 || W <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape n=%d h=%d w=%d", n, H, W);
@@ -967,6 +1062,9 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     int64_t ws_per_lr_pixel = 0;      // workspace bytes per LR pixel
     for (const WsBuf& b : h->bufs) ws_per_lr_pixel += (int64_t)b.res * b.res * b.stride * (int64_t)sizeof(float);
     const int64_t pass_pixels = std::min<int64_t>(h->sub_batch_pixels, h->workspace_budget / std::max<int64_t>(ws_per_lr_pixel, 1));
+    // sub_batch_pixels is a soft knob (a pass holds at least one image); the workspace budget is the hard one
+    const int64_t budget_pixels = h->workspace_budget / std::max<int64_t>(ws_per_lr_pixel, 1);
+    if (per_image > budget_pixels && h->spatial_tiling) return run_tiled(h, x, x2, y, n, H, W, budget_pixels, stream);
     int nb = (int)std::max<int64_t>(1, std::min<int64_t>(n, pass_pixels / per_image));
     int rc = ensure_workspace(h, nb, H, W);
     if (rc) return rc;
@@ -1213,6 +1311,10 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
         h->workspace_budget = value;
         return DCSCN_OK;
     }
+    if (!strcmp(key, "spatial_tiling")) {
+        h->spatial_tiling = value != 0;
+        return DCSCN_OK;
+    }
     if (!strcmp(key, "fold_linear_tail")) {
         if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the fold_linear_tail option must be set before dcscn_finalize");
         h->fold_tail = value != 0;
@@ -1362,6 +1464,8 @@ int dcscn_destroy(dcscn_handle h) {
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (void* p : h->device_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
+    for (float* p : {h->tile_x, h->tile_x2, h->tile_y})
+        if (p) (void)hipFree(p);
     if (h->io_x) (void)hipFree(h->io_x);
     if (h->io_x2) (void)hipFree(h->io_x2);
     if (h->io_y) (void)hipFree(h->io_y);

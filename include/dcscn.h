@@ -148,7 +148,9 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
 
 /* Tunables: "sub_batch_pixels" (LR pixels processed per pass through the layer chain, default 4 Mi),
  * "workspace_budget_bytes" (caps the pass size so the activation workspace stays below it, default
- * 48 GiB), "profile" (1: time every launch with HIP events, read back with dcscn_get_profile),
+ * 48 GiB; an image whose workspace alone exceeds it is cut into equally shaped windows overlapping by twice
+ * the network's receptive-field radius, run as a batch and stitched -- "spatial_tiling" 0 disables that and
+ * lets the allocation fail instead), "profile" (1: time every launch with HIP events, read back with dcscn_get_profile),
  * "winograd" (default 1; before dcscn_finalize only: 0 keeps every 3x3 conv on the direct
  * implicit-GEMM kernel instead of the Winograd F(2x2,3x3) kernel),
  * "fold_linear_tail" (default 0; before dcscn_finalize only: 1 runs the last pixel-shuffler conv,

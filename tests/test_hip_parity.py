@@ -259,3 +259,45 @@ def test_folded_tail_not_applicable(oracle, variant):
         assert not _folded(eng)
         y = eng.forward(x, x2)
     assert float(np.max(np.abs(y - ref))) <= MAX_ABS_TOL
+
+
+# ---- images larger than the workspace budget: haloed spatial windows (api.hip run_tiled) ----------------
+
+@pytest.mark.parametrize("fold", [False, True])
+@pytest.mark.parametrize("case", [
+    (dict(layers=3, filters=16, min_filters=8), 1, 70, 90),                 # x2, halo 3+1+1+1
+    (dict(layers=3, filters=16, min_filters=8, scale=3), 2, 45, 61),        # two images, x3
+    (dict(layers=4, filters=12, min_filters=8, scale=4, pixel_shuffler_filters=4), 1, 64, 40),   # two PS stages
+    (dict(layers=3, filters=16, min_filters=8), 1, 200, 20),                # tiled along one axis only
+])
+def test_spatial_tiling(oracle, case, fold):
+    """With a workspace budget smaller than one image the library cuts windows with a receptive-field halo, runs
+    them as a batch and stitches; the result must meet the same bar against the oracle of the WHOLE image (SAME
+    padding only acts at true image borders) and agree with the untiled pass to rounding."""
+    flags, n, h, w = case
+    cfg = oracle.make_config(**flags)
+    weights = oracle.synthetic_weights(cfg, seed=2)
+    x, x2 = synthetic_batch(n, h, w, cfg["scale"], seed=3)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with _fold_engine(cfg, weights, fold=fold) as eng:
+        whole = eng.forward(x, x2)
+        per_px = eng.workspace_bytes() // (n * h * w) + 1
+        eng.set_option("workspace_budget_bytes", per_px * 30 * 34)          # windows of about 30 x 34 LR pixels
+        tiled = eng.forward(x, x2)
+        eng.set_option("spatial_tiling", 0)
+        untiled_again = eng.forward(x, x2)                                   # tiling off: one big pass as before
+    assert float(np.max(np.abs(tiled - ref))) <= MAX_ABS_TOL
+    assert float(np.max(np.abs(tiled - whole))) <= 6.2e-5      # two f32 ulps at 256..512: different Winograd tile phase
+    assert np.array_equal(untiled_again, whole)
+
+
+def test_spatial_tiling_window_too_small(oracle):
+    from dcscn_amd import engine
+    cfg = oracle.make_config(layers=3, filters=16, min_filters=8)
+    weights = oracle.synthetic_weights(cfg, seed=2)
+    x, x2 = synthetic_batch(1, 40, 40, 2, seed=3)
+    with _fold_engine(cfg, weights, fold=False) as eng:
+        eng.forward(x, x2)
+        eng.set_option("workspace_budget_bytes", 1)
+        with pytest.raises(engine.EngineError):
+            eng.forward(x, x2)
