@@ -291,7 +291,8 @@ void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_nam
               !dst.residual;
     const int64_t out_bytes = 4 * r2 * dst.width;
 
-    if (ds && src.buf >= 0 && cin == 1 && cout == 1 && dst.buf == EXT_Y && !bias && activator == DCSCN_ACT_NONE) {
+    if (ds && src.buf >= 0 && cin == 1 && cout == 1 && dst.buf == EXT_Y && !bias && activator == DCSCN_ACT_NONE &&
+        cout1_lds_bytes(ks, src.cin_phys) <= 64 * 1024) {
         // separable 1 -> 1 conv (R-CNN of the c-DCSCN DS models): depthwise sum, times the pointwise
         // scalar, plus the residual -- one launch of the single-output kernel
         op.kind = OP_COUT1;
@@ -304,8 +305,9 @@ void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_nam
         op.dw_w = t_dw;
         op.macs = li.macs_per_lr_pixel;
         op.bytes = 4 * r2 * src.cin_phys + out_bytes + (dst.residual ? 4 * r2 : 0);
-    } else if (ds && src.buf >= 0) {
+    } else if (ds && src.buf >= 0 && ks <= 3) {
         // depthwise half fused into the staging of the pointwise GEMM: its output never touches HBM
+        // (instantiated for 1x1 / 3x3 depthwise filters; --cnn_size=5/7 separable models take the two-launch form below)
         op.kind = OP_CONV;
         op.ks = 1;
         op.dwk = ks;
@@ -318,8 +320,8 @@ void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_nam
         op.macs = li.macs_per_lr_pixel;
         op.bytes = 4 * r2 * src.cin_phys + out_bytes + (dst.residual ? 4 * r2 : 0);
     } else if (ds) {
-        // first layer (reads the 1-channel external input): depthwise half -> DW scratch (logical channel
-        // order, zero padded to 4), then the pointwise GEMM
+        // first layer (reads the 1-channel external input), or a 5x5 / 7x7 depthwise filter: depthwise half ->
+        // DW scratch (logical channel order, zero padded to 4), then the pointwise GEMM
         if (*dw_buf < 0) *dw_buf = new_buf(h, 4, 1);
         Op dw;
         dw.kind = OP_DW;
@@ -357,8 +359,8 @@ void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_nam
         op.macs = r2 * (int64_t)ks * ks * cout;
         op.bytes = 4 * r2 + out_bytes;
     } else {
-        const bool to_y = cout == 1 && dst.buf == EXT_Y && !bias && activator == DCSCN_ACT_NONE &&
-                          (size_t)ks * ks * (src.cin_phys + 328) * sizeof(float) <= 64 * 1024;
+        const bool to_y = cout == 1 && dst.buf == EXT_Y && !bias && activator == DCSCN_ACT_NONE && ks <= 5 &&
+                          cout1_lds_bytes(ks, src.cin_phys) <= 64 * 1024;
         op.kind = to_y ? OP_COUT1 : OP_CONV;
         op.ks = ks;
         op.cin = cin;
@@ -564,6 +566,9 @@ int build_graph(dcscn_ctx* h) {
         add_conv(h, nm, nm, src, k, 1, false, DCSCN_ACT_NONE, ds, d, &dw_buf);
     }
     if (src.res != c.scale) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: output resolution %d != scale %d", src.res, c.scale);
+    for (const Op& op : h->ops)
+        if (op.kind == OP_CIN1 && cin1_lds_bytes(op.ks, pad4(op.cout)) > 64 * 1024)
+            return fail(h, DCSCN_ERR_UNSUPPORTED, "first layer %dx%d with %d filters needs more than 64 KB of LDS", op.ks, op.ks, op.cout);
 
     // size the depthwise scratch: widest separable input at its resolution (per pixel: stride floats)
     if (dw_buf >= 0) {
@@ -797,7 +802,7 @@ int finalize_op(dcscn_ctx* h, Op& op) {
         if (!rcw) rcw = upload(h, alpha.data(), alpha.size() * sizeof(float), (void**)&op.d_alpha);
         return rcw;
     }
-    const int max_nt = op.dwk ? conv_max_fused_dw_nt() : 13;
+    const int max_nt = op.dwk ? conv_max_fused_dw_nt() : conv_max_nt(op.ks);
     op.n_tiles = (tiles16 + max_nt - 1) / max_nt;
     const int nt = (tiles16 + op.n_tiles - 1) / op.n_tiles;
     op.shape = conv_pick_shape(op.ks, nt, op.dwk);
@@ -1161,7 +1166,8 @@ int dcscn_create(const dcscn_config* cfg, int device, dcscn_handle* out) {
     if (c.scale < 2 || c.scale > 4) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "scale %d (supported: 2, 3, 4)", c.scale);
     if (c.layers < 1 || c.layers > 256 || c.filters < 1) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "bad layers/filters");
     if (c.layers > 1 && !(c.filters_decay_gamma > 0.0)) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "filters_decay_gamma must be > 0");
-    if (c.cnn_size != 3 && c.cnn_size != 1) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "cnn_size %d (supported: 3, 1)", c.cnn_size);
+    if (c.cnn_size != 1 && c.cnn_size != 3 && c.cnn_size != 5 && c.cnn_size != 7)
+        return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "cnn_size %d (supported: 1, 3, 5, 7)", c.cnn_size);
     if (c.channels != 1) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "channels %d (the reference itself only supports 1)", c.channels);
     if (!c.pixel_shuffler && c.depthwise_separable)
         return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "transposed-conv upsampler together with depthwise_separable is not implemented");

@@ -197,32 +197,45 @@ __global__ __launch_bounds__(256, WPS) void conv_igemm(const ConvArgs a) {
     const int a_lane = lk * G::PS + wave * MT * G::HTW + lj;
     const int b_lane = G::A_FLOATS + lk * G::NS + lj;
 
-    auto compute = [&](const float* buf) DCSCN_INL {
-        const float* As = buf + a_lane;
-        const float* Bs = buf + b_lane;
-        static_for<0, G::TAPS>([&](auto tap_) DCSCN_INL {
-            constexpr int tap = decltype(tap_)::value;
-            constexpr int dy = tap / KS, dx = tap % KS;
-            static_for<0, G::KQ>([&](auto ks_) DCSCN_INL {
-                constexpr int ks = decltype(ks_)::value;
-                float xv[MT], wv[NT];
-                static_for<0, MT>([&](auto m_) DCSCN_INL {
-                    constexpr int m = decltype(m_)::value;
-                    xv[m] = As[(ks * 4) * G::PS + (m + dy) * G::HTW + dx];
-                });
+    // one filter tap (dy, dx): KQ k-steps of MT*NT MFMAs; As / Bs already point at the tap's row
+    auto compute_tap = [&](const float* As, const float* Bs, auto dx_) DCSCN_INL {
+        constexpr int dx = decltype(dx_)::value;
+        static_for<0, G::KQ>([&](auto ks_) DCSCN_INL {
+            constexpr int ks = decltype(ks_)::value;
+            float xv[MT], wv[NT];
+            static_for<0, MT>([&](auto m_) DCSCN_INL {
+                constexpr int m = decltype(m_)::value;
+                xv[m] = As[(ks * 4) * G::PS + m * G::HTW + dx];
+            });
+            static_for<0, NT>([&](auto n_) DCSCN_INL {
+                constexpr int n = decltype(n_)::value;
+                wv[n] = Bs[(dx * KC + ks * 4) * G::NS + n * 16];
+            });
+            static_for<0, MT>([&](auto m_) DCSCN_INL {
+                constexpr int m = decltype(m_)::value;
                 static_for<0, NT>([&](auto n_) DCSCN_INL {
                     constexpr int n = decltype(n_)::value;
-                    wv[n] = Bs[(tap * KC + ks * 4) * G::NS + n * 16];
-                });
-                static_for<0, MT>([&](auto m_) DCSCN_INL {
-                    constexpr int m = decltype(m_)::value;
-                    static_for<0, NT>([&](auto n_) DCSCN_INL {
-                        constexpr int n = decltype(n_)::value;
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[n], xv[m], acc[m][n], 0, 0, 0);
-                    });
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[n], xv[m], acc[m][n], 0, 0, 0);
                 });
             });
         });
+    };
+    auto compute = [&](const float* buf) DCSCN_INL {
+        const float* As = buf + a_lane;
+        const float* Bs = buf + b_lane;
+        if constexpr (KS <= 3) {
+            // fully unrolled over the taps: every LDS offset is an immediate
+            static_for<0, KS>([&](auto dy_) DCSCN_INL {
+                constexpr int dy = decltype(dy_)::value;
+                static_for<0, KS>([&](auto dx_) DCSCN_INL { compute_tap(As + dy * G::HTW, Bs + dy * KS * KC * G::NS, dx_); });
+            });
+        } else {
+            // 5x5 / 7x7: the tap rows are a real loop (25-49 unrolled taps of MT*NT MFMAs would only bloat the
+            // kernel); accumulators stay statically indexed, only the two LDS base addresses advance
+#pragma unroll 1
+            for (int dy = 0; dy < KS; ++dy, As += G::HTW, Bs += KS * KC * G::NS)
+                static_for<0, KS>([&](auto dx_) DCSCN_INL { compute_tap(As, Bs, dx_); });
+        }
     };
 
     // ---- K loop ----

@@ -57,10 +57,13 @@ hipError_t conv_init_k1();
 hipError_t conv_init_k3();
 hipError_t conv_launch_k1(int nt, int dwk, const ConvArgs& a, int n_tiles, hipStream_t stream);
 hipError_t conv_launch_k3(int nt, const ConvArgs& a, int n_tiles, hipStream_t stream);
-// 5x5: only the channel-tile counts the folded linear tail needs (ceil(s*s / 4) for pixel-shuffler block s <= 4)
-#define DCSCN_FOR_NT_K5(X) X(5, 1) X(5, 2) X(5, 3) X(5, 4)
-constexpr int kMaxK5Nt = 4;
+// 5x5 (--cnn_size=5 and the folded linear tail) and 7x7 (--cnn_size=7); the 7x7 filter block of 49 taps
+// limits the channel tile to 8 x 16 (113 KB of LDS)
+#define DCSCN_FOR_NT_K7(X) X(7, 1) X(7, 2) X(7, 3) X(7, 4) X(7, 5) X(7, 6) X(7, 7) X(7, 8)
+constexpr int kMaxK7Nt = 8;
 hipError_t conv_init_k5();
+hipError_t conv_init_k7();
 hipError_t conv_launch_k5(int nt, const ConvArgs& a, int n_tiles, hipStream_t stream);
+hipError_t conv_launch_k7(int nt, const ConvArgs& a, int n_tiles, hipStream_t stream);
 
 }  // namespace dcscn

@@ -91,6 +91,11 @@ __host__ __device__ constexpr int wino_glb_col(int nt, int jn) { return kWinoBVe
 hipError_t wino_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
 int conv_max_fused_dw_nt();
+// widest channel tile (units of 16) of the conv_igemm<ks, ...> family
+int conv_max_nt(int ks);
+// LDS bytes of conv_cin1 / conv_cout1 for a kernel size (both must fit 64 KB)
+inline size_t cin1_lds_bytes(int ks, int cs) { const int ht = 16 + 2 * (ks / 2); return (size_t)(((ht * ht + 3) & ~3) + (ks * ks + 2) * cs) * sizeof(float); }
+inline size_t cout1_lds_bytes(int ks, int cin_phys) { const int ht = 16 + 2 * (ks / 2); return (size_t)(ks * ks * cin_phys + ks * ks * ((ht * ht + 3) & ~3)) * sizeof(float); }
 
 // First layer: 3x3 (or 1x1) conv from ONE input channel, direct form (write-bound).
 struct Cin1Args {

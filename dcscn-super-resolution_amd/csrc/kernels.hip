@@ -19,11 +19,13 @@ namespace dcscn {
 ConvShape conv_pick_shape(int ks, int nt, int dwk) { return ConvShape{ks, pick_mt(ks, nt), nt, pick_kc(ks, nt), dwk}; }
 size_t conv_lds_bytes(const ConvShape& s) { return lds_bytes_for(s.ks, s.mt, s.nt, s.kc); }
 int conv_max_fused_dw_nt() { return kMaxDwNt; }
+int conv_max_nt(int ks) { return ks == 7 ? kMaxK7Nt : 13; }
 
 hipError_t conv_init_kernels() {
     hipError_t e = conv_init_k1();
     if (e == hipSuccess) e = conv_init_k3();
-    return e != hipSuccess ? e : conv_init_k5();
+    if (e == hipSuccess) e = conv_init_k5();
+    return e != hipSuccess ? e : conv_init_k7();
 }
 
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream) {
@@ -31,7 +33,8 @@ hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipSt
     if (s.dwk != 0 && (s.ks != 1 || a.dww == nullptr || a.dwk != s.dwk)) return hipErrorInvalidValue;
     if (s.ks == 1) return conv_launch_k1(s.nt, s.dwk, a, n_tiles, stream);
     if (s.ks == 3) return conv_launch_k3(s.nt, a, n_tiles, stream);
-    if (s.ks == 5 && s.nt <= kMaxK5Nt) return conv_launch_k5(s.nt, a, n_tiles, stream);
+    if (s.ks == 5) return conv_launch_k5(s.nt, a, n_tiles, stream);
+    if (s.ks == 7 && s.nt <= kMaxK7Nt) return conv_launch_k7(s.nt, a, n_tiles, stream);
     return hipErrorInvalidValue;
 }
 
@@ -114,8 +117,11 @@ hipError_t cin1_launch(const Cin1Args& a, hipStream_t stream) {
     const int ht = 16 + 2 * halo;
     const size_t lds = (size_t)(((ht * ht + 3) & ~3) + (a.ks * a.ks + 2) * a.cs) * sizeof(float);
     const dim3 grid((unsigned)(a.N * tiles));
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
     if (a.ks == 3) hipLaunchKernelGGL(conv_cin1<3>, grid, dim3(256), lds, stream, a, tpp_log2);
     else if (a.ks == 1) hipLaunchKernelGGL(conv_cin1<1>, grid, dim3(256), lds, stream, a, tpp_log2);
+    else if (a.ks == 5) hipLaunchKernelGGL(conv_cin1<5>, grid, dim3(256), lds, stream, a, tpp_log2);
+    else if (a.ks == 7) hipLaunchKernelGGL(conv_cin1<7>, grid, dim3(256), lds, stream, a, tpp_log2);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -207,6 +213,9 @@ hipError_t cout1_launch(const Cout1Args& a, hipStream_t stream) {
     } else if (a.ks == 1) {
         if (narrow) hipLaunchKernelGGL((conv_cout1<1, 1>), grid, dim3(256), lds, stream, a);
         else hipLaunchKernelGGL((conv_cout1<1, 8>), grid, dim3(256), lds, stream, a);
+    } else if (a.ks == 5) {
+        if (narrow) hipLaunchKernelGGL((conv_cout1<5, 1>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((conv_cout1<5, 8>), grid, dim3(256), lds, stream, a);
     } else {
         return hipErrorInvalidValue;
     }

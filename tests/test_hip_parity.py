@@ -97,6 +97,13 @@ def test_sub_batching_is_transparent(oracle):
     dict(layers=3, filters=16, min_filters=8, activator="leaky_relu"),
     dict(layers=3, filters=16, min_filters=0),
     dict(layers=2, filters=8, min_filters=8, cnn_size=1),
+    # --cnn_size=5 / 7: every conv of the graph (feature stack, B2, pixel shuffler, reconstruction) is k x k
+    dict(layers=3, filters=20, min_filters=8, cnn_size=5),
+    dict(layers=2, filters=40, min_filters=24, cnn_size=7, nin_filters=20, nin_filters2=12),
+    dict(layers=3, filters=16, min_filters=8, cnn_size=5, scale=3, reconstruct_layers=2, reconstruct_filters=8),
+    dict(layers=2, filters=12, min_filters=8, cnn_size=5, depthwise_separable=True),
+    dict(layers=2, filters=12, min_filters=8, cnn_size=7, depthwise_separable=True, scale=4),
+    dict(layers=2, filters=12, min_filters=8, cnn_size=5, pixel_shuffler=False),
     dict(layers=3, filters=16, min_filters=8, depthwise_separable=True, scale=2),
     dict(layers=3, filters=16, min_filters=8, depthwise_separable=True, use_nin=False, scale=3),
     # transposed-conv upsampler (tf_graph.py:219-236), k = 4 / 5 / 8
