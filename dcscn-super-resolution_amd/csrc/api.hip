@@ -129,6 +129,11 @@ struct dcscn_ctx {
     // host-path staging
     float* io_x = nullptr; float* io_x2 = nullptr; float* io_y = nullptr;
     size_t io_x_cap = 0, io_y_cap = 0;
+    // bicubic resize (resample.hip): Pillow coefficient tables per (in, out) size, and the intermediate image
+    struct ResampleTable { int ksize = 0; int* d_bounds = nullptr; double* d_kk = nullptr; };
+    std::map<std::pair<int, int>, ResampleTable> resample_tables;
+    float* rs_tmp = nullptr; size_t rs_tmp_cap = 0;
+    float* rs_in = nullptr; float* rs_out = nullptr; size_t rs_in_cap = 0, rs_out_cap = 0;
     // spatial tiling of images larger than one pass (run_tiled): gathered tile batch
     float* tile_x = nullptr; float* tile_x2 = nullptr; float* tile_y = nullptr;
     size_t tile_x_cap = 0, tile_y_cap = 0;
@@ -1109,6 +1114,65 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     return DCSCN_OK;
 }
 
+// ---- Pillow-compatible bicubic resize on the device (resample.hip) -------------------------------------
+int resample_table(dcscn_ctx* h, int in_size, int out_size, const dcscn_ctx::ResampleTable** out) {
+    auto key = std::make_pair(in_size, out_size);
+    auto it = h->resample_tables.find(key);
+    if (it == h->resample_tables.end()) {
+        std::vector<int> bounds;
+        std::vector<double> kk;
+        dcscn_ctx::ResampleTable t;
+        t.ksize = resample_coeffs(in_size, out_size, &bounds, &kk);
+        int rc = upload(h, bounds.data(), bounds.size() * sizeof(int), (void**)&t.d_bounds);
+        if (!rc) rc = upload(h, kk.data(), kk.size() * sizeof(double), (void**)&t.d_kk);
+        if (rc) return rc;
+        it = h->resample_tables.emplace(key, t).first;
+    }
+    *out = &it->second;
+    return DCSCN_OK;
+}
+
+int grow(dcscn_ctx* h, float** p, size_t* cap, size_t floats, hipStream_t stream) {
+    if (floats <= *cap) return DCSCN_OK;
+    HIP_TRY(h, hipStreamSynchronize(stream));
+    if (*p) HIP_TRY(h, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    hipError_t e = hipMalloc((void**)p, floats * sizeof(float));
+    if (e != hipSuccess) return fail(h, DCSCN_ERR_NOMEM, "buffer of %zu floats: %s", floats, hipGetErrorString(e));
+    *cap = floats;
+    return DCSCN_OK;
+}
+
+// [n, H, W] -> [n, OH, OW], device pointers; horizontal pass first, as Pillow (a pass whose size does not
+// change is skipped there too, so it adds no rounding)
+int resize_device(dcscn_ctx* h, const float* in, float* out, int n, int H, int W, int OH, int OW, hipStream_t stream) {
+    if (n <= 0) return DCSCN_OK;
+    const float* src = in;
+    if (OW != W) {
+        const dcscn_ctx::ResampleTable* t;
+        int rc = resample_table(h, W, OW, &t);
+        if (rc) return rc;
+        float* dst = out;
+        if (OH != H) {
+            rc = grow(h, &h->rs_tmp, &h->rs_tmp_cap, (size_t)n * H * OW, stream);
+            if (rc) return rc;
+            dst = h->rs_tmp;
+        }
+        HIP_TRY(h, resample_h_launch(src, dst, t->d_bounds, t->d_kk, t->ksize, (long long)n * H, W, OW, stream));
+        src = dst;
+    }
+    if (OH != H) {
+        const dcscn_ctx::ResampleTable* t;
+        int rc = resample_table(h, H, OH, &t);
+        if (rc) return rc;
+        HIP_TRY(h, resample_v_launch(src, out, t->d_bounds, t->d_kk, t->ksize, n, H, OH, OW, stream));
+    } else if (OW == W) {
+        HIP_TRY(h, hipMemcpyAsync(out, in, (size_t)n * H * W * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    return DCSCN_OK;
+}
+
 // flip / rotate index maps of helper/utilty.py:595-617: transformed[r][c] = image[src_r][src_c]
 inline void flip_src(int type, int h, int w, int r, int c, int* sr, int* sc) {
     switch (type) {
@@ -1383,6 +1447,56 @@ int dcscn_forward(dcscn_handle h, const float* x, const float* x2, float* y, int
     return DCSCN_OK;
 }
 
+int dcscn_resize_bicubic(dcscn_handle h, const float* in, float* out, int n, int height, int width, int out_height, int out_width) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (n < 0 || height <= 0 || width <= 0 || out_height <= 0 || out_width <= 0)
+        return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape n=%d %dx%d -> %dx%d", n, height, width, out_height, out_width);
+    if (n == 0) return DCSCN_OK;
+    if (!in || !out) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t ni = (size_t)n * height * width, no = (size_t)n * out_height * out_width;
+    int rc = grow(h, &h->rs_in, &h->rs_in_cap, ni, h->stream);
+    if (!rc) rc = grow(h, &h->rs_out, &h->rs_out_cap, no, h->stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->rs_in, in, ni * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    rc = resize_device(h, h->rs_in, h->rs_out, n, height, width, out_height, out_width, h->stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out, h->rs_out, no * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DCSCN_OK;
+}
+
+int dcscn_resize_bicubic_device(dcscn_handle h, const float* in, float* out, int n, int height, int width, int out_height,
+                                int out_width, void* stream) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (n < 0 || height <= 0 || width <= 0 || out_height <= 0 || out_width <= 0)
+        return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape n=%d %dx%d -> %dx%d", n, height, width, out_height, out_width);
+    if (n == 0) return DCSCN_OK;
+    if (!in || !out) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return resize_device(h, in, out, n, height, width, out_height, out_width, stream ? (hipStream_t)stream : h->stream);
+}
+
+int dcscn_forward_lr(dcscn_handle h, const float* x, float* y, int n, int height, int width) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_forward_lr before dcscn_finalize");
+    if (n < 0 || height <= 0 || width <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape n=%d h=%d w=%d", n, height, width);
+    if (n == 0) return DCSCN_OK;
+    if (!x || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int s = h->cfg.scale;
+    const size_t lr = (size_t)n * height * width, hr = lr * s * s;
+    int rc = ensure_io(h, lr, hr);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(h->io_x, x, lr * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    rc = resize_device(h, h->io_x, h->io_x2, n, height, width, height * s, width * s, h->stream);   // DCSCN.py:552-554
+    if (!rc) rc = run_forward(h, h->io_x, h->io_x2, h->io_y, n, height, width, h->stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(y, h->io_y, hr * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DCSCN_OK;
+}
+
 int dcscn_forward_ensemble(dcscn_handle h, const float* x, const float* x2, double* y, int height, int width, int n_ensemble) {
     if (!h) return DCSCN_ERR_INVALID_ARG;
     if (!x || !x2 || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
@@ -1470,7 +1584,7 @@ int dcscn_destroy(dcscn_handle h) {
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (void* p : h->device_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
-    for (float* p : {h->tile_x, h->tile_x2, h->tile_y})
+    for (float* p : {h->tile_x, h->tile_x2, h->tile_y, h->rs_tmp, h->rs_in, h->rs_out})
         if (p) (void)hipFree(p);
     if (h->io_x) (void)hipFree(h->io_x);
     if (h->io_x2) (void)hipFree(h->io_x2);

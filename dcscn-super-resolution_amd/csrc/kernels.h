@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace dcscn {
 
 // Activation codes as the kernels see them (build_activator, helper/tf_graph.py:77-102).
@@ -91,6 +93,13 @@ __host__ __device__ constexpr int wino_glb_col(int nt, int jn) { return kWinoBVe
 hipError_t wino_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
 int conv_max_fused_dw_nt();
+
+// Pillow-compatible bicubic resize of 1-channel float images (resample.hip)
+int resample_coeffs(int in_size, int out_size, std::vector<int>* bounds, std::vector<double>* kk);   // returns ksize
+hipError_t resample_h_launch(const float* in, float* out, const int* bounds, const double* kk, int ksize,
+                             long long rows, int w, int ow, hipStream_t stream);
+hipError_t resample_v_launch(const float* in, float* out, const int* bounds, const double* kk, int ksize,
+                             int n_img, int h, int oh, int w, hipStream_t stream);
 // widest channel tile (units of 16) of the conv_igemm<ks, ...> family
 int conv_max_nt(int ks);
 // LDS bytes of conv_cin1 / conv_cout1 for a kernel size (both must fit 64 KB)

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     "dcscn_num_tensors", "dcscn_tensor_info", "dcscn_set_tensor", "dcscn_finalize", "dcscn_num_layers",
     "dcscn_layer_info_get", "dcscn_num_ops", "dcscn_op_info_get", "dcscn_set_option", "dcscn_forward",
     "dcscn_forward_device", "dcscn_forward_ensemble", "dcscn_get_profile", "dcscn_workspace_bytes",
-    "dcscn_last_error", "dcscn_destroy",
+    "dcscn_last_error", "dcscn_destroy", "dcscn_resize_bicubic", "dcscn_resize_bicubic_device", "dcscn_forward_lr",
 )
 
 
@@ -132,6 +132,9 @@ def load_library():
     lib.dcscn_forward.argtypes = [vp, fp, fp, fp, c.c_int, c.c_int, c.c_int]
     lib.dcscn_forward_device.argtypes = [vp, vp, vp, vp, c.c_int, c.c_int, c.c_int, vp]
     lib.dcscn_forward_ensemble.argtypes = [vp, fp, fp, dp, c.c_int, c.c_int, c.c_int]
+    lib.dcscn_resize_bicubic.argtypes = [vp, fp, fp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int]
+    lib.dcscn_resize_bicubic_device.argtypes = [vp, vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp]
+    lib.dcscn_forward_lr.argtypes = [vp, fp, fp, c.c_int, c.c_int, c.c_int]
     lib.dcscn_get_profile.argtypes = [vp, dp, c.c_int]
     lib.dcscn_workspace_bytes.argtypes = [vp]
     lib.dcscn_workspace_bytes.restype = c.c_int64
@@ -303,6 +306,32 @@ class Engine:
         self._check(self._lib.dcscn_forward(self._h, x.ctypes.data_as(fp), x2.ctypes.data_as(fp),
                                             y.ctypes.data_as(fp), n, h, w))
         return y
+
+    def forward_lr(self, x):
+        """``do(input_image, bicubic_input_image=None)`` (DCSCN.py:547-554): x [n, h, w, 1] (or [n, h, w]); the bicubic
+        x2 is computed on the device, bit-compatible with Pillow.  Returns y [n, s*h, s*w, 1]."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim == 4:
+            x = x[..., 0]
+        n, h, w = x.shape
+        s = self.scale
+        y = np.empty((n, h * s, w * s, 1), np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        self._check(self._lib.dcscn_forward_lr(self._h, np.ascontiguousarray(x).ctypes.data_as(fp), y.ctypes.data_as(fp), n, h, w))
+        return y
+
+    def resize_bicubic(self, images, out_height, out_width):
+        """Pillow-compatible (mode 'F', BICUBIC) resize of [n, h, w] float images on the device -> [n, oh, ow]."""
+        a = np.ascontiguousarray(images, dtype=np.float32)
+        single = a.ndim == 2
+        if single:
+            a = a[None]
+        n, h, w = a.shape
+        out = np.empty((n, int(out_height), int(out_width)), np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        self._check(self._lib.dcscn_resize_bicubic(self._h, a.ctypes.data_as(fp), out.ctypes.data_as(fp), n, h, w,
+                                                   int(out_height), int(out_width)))
+        return out[0] if single else out
 
     def forward_device(self, x_ptr, x2_ptr, y_ptr, n, h, w, stream=None):
         """Enqueue on device pointers (ints, e.g. ``torch.Tensor.data_ptr()``); does not synchronise."""

@@ -263,7 +263,15 @@ class SuperResolution:
         ch = input_image.shape[2] if len(input_image.shape) > 2 else 1
         if ch != 1:
             raise ValueError("do() expects a single-channel image, got %d channels" % ch)
-        if bicubic_input_image is None:
+        if bicubic_input_image is None and self.resampling_method == "bicubic":
+            # DCSCN.py:552-554 on the device: dcscn_resize_bicubic is bit-compatible with Pillow's mode-'F' BICUBIC
+            # (tests/test_resize_hip.py), so x2 never has to be built or uploaded by the host
+            eng = self._ready_engine()
+            x = np.ascontiguousarray(input_image, dtype=np.float32).reshape(h, w)
+            if self.max_value == 255.0 and self.self_ensemble <= 1:
+                return eng.forward_lr(x[None])[0]
+            bicubic_input_image = eng.resize_bicubic(x, self.scale * h, self.scale * w).reshape(self.scale * h, self.scale * w, 1)
+        elif bicubic_input_image is None:
             bicubic_input_image = util.resize_image_by_pil(input_image, self.scale,
                                                            resampling_method=self.resampling_method)
         if self.max_value != 255.0:

@@ -163,6 +163,20 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value);
 /* Forward pass on host buffers: H2D, kernels, D2H, synchronous. */
 int dcscn_forward(dcscn_handle h, const float* x, const float* x2, float* y, int n, int height, int width);
 
+/* Bicubic resize of `n` single-channel float images [height, width] -> [out_height, out_width], bit-compatible
+ * with Pillow's Image.resize(BICUBIC) on mode-"F" images (a = -0.5 cubic, antialiased when shrinking, float64
+ * accumulation, horizontal pass first): replaces util.resize_image_by_pil (helper/utilty.py:211-239) for the
+ * single-channel images of the path.  Host buffers, synchronous; the _device form takes device pointers and a
+ * hipStream_t (NULL = the handle's stream) and does not synchronise.  Usable before dcscn_finalize. */
+int dcscn_resize_bicubic(dcscn_handle h, const float* in, float* out, int n, int height, int width,
+                         int out_height, int out_width);
+int dcscn_resize_bicubic_device(dcscn_handle h, const float* in, float* out, int n, int height, int width,
+                                int out_height, int out_width, void* stream);
+
+/* do(input_image, bicubic_input_image=None) (DCSCN.py:547-554): x2 is the bicubic upscale of x, computed on the
+ * device with dcscn_resize_bicubic; otherwise as dcscn_forward. */
+int dcscn_forward_lr(dcscn_handle h, const float* x, float* y, int n, int height, int width);
+
 /* Forward pass on device buffers, enqueued on `stream` (a hipStream_t, NULL = the handle's own
  * stream) without synchronising.  Workspace growth (first call / larger shape) does synchronise. */
 int dcscn_forward_device(dcscn_handle h, const float* x, const float* x2, float* y,
