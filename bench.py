@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--ops", action="store_true", help="print the per-launch table to stderr")
     ap.add_argument("--no-winograd", action="store_true", help="keep the 3x3 convs on the direct implicit-GEMM kernel")
     ap.add_argument("--cpu-sample", type=int, default=64, help="patches in the CPU baseline sample")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive timing of the host-buffer entry points")
     ap.add_argument("--no-opt-in", action="store_true", help="skip the extra timing of the opt-in folded tail")
     ap.add_argument("--fold-tail", action="store_true",
                     help="opt into the folded linear tail (include/dcscn.h: fold_linear_tail); the default runs the reference's layers one by one")
@@ -232,6 +233,31 @@ def main():
                           "(TensorFlow not installable), best of 2 after 1 warm-up per thread setting, %.2f s/forward" % (cs, n, sec),
                 "max_abs_diff_vs_hip": dev_err,
             }
+        if world == 1 and not args.no_host_path:
+            # PCIe-inclusive rate of the host-buffer entry points (never `value`): numpy in, numpy out, synchronous
+            try:
+                # numpy-owned copies: buffers handed out by torch's CPU allocator upload 20x slower through hipMemcpy
+                xh, x2h = x.cpu().numpy().copy(), x2.cpu().numpy().copy()
+                eng.forward(xh, x2h)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    eng.forward(xh, x2h)
+                th = (time.perf_counter() - t1) / 3
+                eng.forward_lr(xh)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    eng.forward_lr(xh)
+                tl = (time.perf_counter() - t1) / 3
+                result["host_path"] = {
+                    "dcscn_forward": {"value": round(lr_pixels / th / 1e6, 4), "ms_per_step": round(th * 1e3, 3),
+                                      "note": "x and x2 uploaded, y downloaded (%.1f MB over PCIe per step)" % ((xh.nbytes + 2 * x2h.nbytes) / 1e6)},
+                    "dcscn_forward_lr": {"value": round(lr_pixels / tl / 1e6, 4), "ms_per_step": round(tl * 1e3, 3),
+                                         "note": "x uploaded, x2 = bicubic(x) built on the device, y downloaded; not comparable to "
+                                                 "`value` input-wise (x2 here is the real bicubic, not noise) but the same work"},
+                    "unit": "LR Mpix/s",
+                }
+            except Exception as exc:
+                result["host_path"] = {"error": str(exc)}
         if world == 1 and not args.fold_tail and not args.no_opt_in:
             # reported beside the headline, never as `value`: the opt-in graph rewrite (same function, fewer
             # FLOPs), timed the same way on the same inputs
