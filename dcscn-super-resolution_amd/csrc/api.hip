@@ -64,7 +64,8 @@ struct WsBuf {
 // one source block of a launch's filter matrix: conv channels [dst, dst + cout) come from `w`
 struct ColSeg {
     int w = -1, b = -1, alpha = -1;   // tensor indices (-1 = absent)
-    int cout = 0;
+    int cout = 0;                     // output channels taken from the tensors ...
+    int col0 = 0;                     // ... starting at this one (a layer split over two launches)
     int dst = 0;
 };
 
@@ -85,6 +86,7 @@ struct Op {
     float out_scale = 1.0f;         // OP_COUT1: pointwise scalar of a separable 1->1 conv
     int tconv_s = 0;                // > 0: the op is tf.nn.conv2d_transpose with this stride, run as its
                                     // equivalent 3x3 conv to s*s*C channels + depth_to_space (see add_tconv)
+    bool wino_tail = false;         // the 1-tile tail group of a layer, split off by split_wino_tails()
     int fold_s = 0;                 // > 0: folded linear tail (see fold_linear_tail): pixel-shuffler block
     int fold_c = 0;                 //      channels after depth_to_space
     int fold_rw = -1;               //      filter tensor of the last reconstruction conv [3, 3, C, 1]
@@ -590,6 +592,59 @@ int build_graph(dcscn_ctx* h) {
     return DCSCN_OK;
 }
 
+// ---- Winograd plan ------------------------------------------------------------------------------------
+int op_tiles16(const Op& op) {
+    int ctot = 0;
+    for (const ColSeg& s : op.segs) ctot = std::max(ctot, s.dst + s.cout);
+    return (ctot + 15) / 16;
+}
+
+// Winograd F(2x2,3x3) for 3x3 convs with enough input channels to amortise the transforms (measured on MI355X:
+// 1.25-1.35x over conv_igemm from 57 input channels up; the tiny layers of the c-DCSCN models stay on the direct
+// kernel).  The Winograd kernel's cost follows its number of channel groups (ceil(tiles / 3)), not its MFMA count:
+// with 4 tiles of 16 (3 + 1) the direct kernel wins (CNN11 66->57: 1.37 vs 1.49 ms), and a single tile gains
+// nothing.  (op.vec4: the Winograd epilogue only has the 16-byte store form.)
+bool wino_eligible(const dcscn_ctx* h, const Op& op) {
+    const int tiles16 = op_tiles16(op);
+    return h->winograd && op.kind == OP_CONV && op.vec4 && op.ks == 3 && op.dwk == 0 && op.cin_phys >= 32 &&
+           op.segs.size() == 1 && op.tconv_s == 0 && tiles16 >= 2 && tiles16 != 4;
+}
+
+// A layer whose 16-channel tiles do not fill groups of 3 ends in a 1-tile group that costs almost as much as a
+// full one in the 3-tile kernel (CNN3 148 = 3+3+3+1 tiles: 1.23 of 6.1 ms): its time is the input-tile loads, not
+// MFMAs.  Such a tail is split off into its own launch of the 1-tile kernel with 8-channel chunks at 4 waves per
+// SIMD (0.85 ms, tools/wino_tune.hip "tail16"); both launches read the same input and write adjacent channel slices.
+void split_wino_tails(dcscn_ctx* h) {
+    std::vector<Op> out;
+    for (const Op& op : h->ops) {
+        const int tiles16 = op_tiles16(op);
+        if (!wino_eligible(h, op) || tiles16 < 7 || tiles16 % 3 != 1 || op.ps != 1 || op.fold_s > 0 || op.segs[0].dst != 0) {
+            out.push_back(op);
+            continue;
+        }
+        const int head = 16 * (tiles16 - 1);              // channels of the full groups
+        Op a = op, b = op;
+        a.cout = head;
+        a.segs[0].cout = head;
+        a.out_width[0] = head;
+        b.name = op.name + " (tail)";
+        b.wino_tail = true;
+        b.cout = op.cout - head;
+        b.segs[0].cout = op.cout - head;
+        b.segs[0].col0 = op.segs[0].col0 + head;
+        b.out_off[0] = op.out_off[0] + head;
+        b.out_width[0] = op.out_width[0] - head;
+        a.macs = op.macs * head / op.cout;
+        b.macs = op.macs - a.macs;
+        const int64_t r2 = (int64_t)op.res * op.res;
+        b.bytes = 4 * r2 * b.out_width[0];               // the input is counted once, with the head
+        a.bytes = op.bytes - b.bytes;
+        out.push_back(a);
+        out.push_back(b);
+    }
+    h->ops.swap(out);
+}
+
 // ---- optional graph rewrite: the linear tail as one conv ----------------------------------------
 //
 // The last pixel-shuffler stage (3x3 conv + bias, NO activator, DCSCN.py:293-311), depth_to_space and the
@@ -757,22 +812,15 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     int ctot = 0;
     for (const ColSeg& s : op.segs) ctot = std::max(ctot, s.dst + s.cout);
     const int tiles16 = (ctot + 15) / 16;
-    // Winograd F(2x2,3x3) for 3x3 convs with enough input channels to amortise the transforms
-    // (measured on MI355X: 1.25-1.35x over conv_igemm from 57 input channels up; the tiny layers of
-    // the c-DCSCN models stay on the direct kernel)
-    // The Winograd kernel's cost follows its number of channel groups (ceil(tiles / 3)), not its MFMA
-    // count: with 4 tiles of 16 (3 + 1) the direct kernel wins (CNN11 66->57: 1.37 vs 1.49 ms), and a
-    // single tile gains nothing.
-    // (op.vec4: the Winograd epilogue only has the 16-byte store form)
-    if (h->winograd && op.vec4 && op.ks == 3 && op.dwk == 0 && op.cin_phys >= 32 && op.segs.size() == 1 &&
-        tiles16 >= 2 && tiles16 != 4) {
+    if (wino_eligible(h, op) || op.wino_tail) {      // see wino_eligible / split_wino_tails
         const int nt = std::min(kWinoMaxNT, tiles16);
-        op.shape = ConvShape{3, 4, nt, kWinoKC, 0, 1};
+        op.shape = ConvShape{3, 4, nt, op.wino_tail ? kWinoTailKC : kWinoKC, 0, 1};
         op.n_tiles = (tiles16 + nt - 1) / nt;
         op.nt_last = tiles16 - (op.n_tiles - 1) * nt;
         op.ctot = op.n_tiles * nt * 16;
-        op.n_chunks = (op.cin_phys + kWinoKC - 1) / kWinoKC;
-        const int ns = wino_glb_ns(nt), kc = kWinoKC;
+        const int kc = op.shape.kc;
+        op.n_chunks = (op.cin_phys + kc - 1) / kc;
+        const int ns = wino_glb_ns(nt);
         const size_t chunk_floats = (size_t)16 * kc * ns;
         // + one staging sweep of slack: the kernel loads the last partial sweep of a chunk with every
         // thread (only the LDS store is predicated), which may run past the final chunk by < 2048 floats
@@ -781,6 +829,7 @@ int finalize_op(dcscn_ctx* h, Op& op) {
         const ColSeg& sg = op.segs[0];
         const TensorSpec& tw = w_override ? *w_override : h->tensors[sg.w];   // [3, 3, cin, cout]
         const int cin = (int)op.chan_map.size();
+        const int wcols = w_override ? sg.cout : (int)tw.shape.back();
         static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         for (int ci = 0; ci < cin; ++ci) {
             const int kp = op.chan_map[ci];
@@ -788,7 +837,7 @@ int finalize_op(dcscn_ctx* h, Op& op) {
             for (int co = 0; co < sg.cout; ++co) {
                 double g[3][3], gg[4][3];
                 for (int i = 0; i < 3; ++i)
-                    for (int j = 0; j < 3; ++j) g[i][j] = tw.data[((size_t)(i * 3 + j) * cin + ci) * sg.cout + co];
+                    for (int j = 0; j < 3; ++j) g[i][j] = tw.data[((size_t)(i * 3 + j) * cin + ci) * wcols + sg.col0 + co];
                 for (int xi = 0; xi < 4; ++xi)                      // G g
                     for (int j = 0; j < 3; ++j) gg[xi][j] = G[xi][0] * g[0][j] + G[xi][1] * g[1][j] + G[xi][2] * g[2][j];
                 const int cc = sg.dst + co;
@@ -801,8 +850,8 @@ int finalize_op(dcscn_ctx* h, Op& op) {
             }
         }
         for (int co = 0; co < sg.cout; ++co) {
-            if (sg.b >= 0) bias[sg.dst + co] = h->tensors[sg.b].data[co];
-            alpha[sg.dst + co] = sg.alpha >= 0 ? h->tensors[sg.alpha].data[co] : op.const_alpha;
+            if (sg.b >= 0) bias[sg.dst + co] = h->tensors[sg.b].data[sg.col0 + co];
+            alpha[sg.dst + co] = sg.alpha >= 0 ? h->tensors[sg.alpha].data[sg.col0 + co] : op.const_alpha;
         }
         int rcw = upload(h, pack.data(), pack.size() * sizeof(float), (void**)&op.d_w);
         if (!rcw) rcw = upload(h, bias.data(), bias.size() * sizeof(float), (void**)&op.d_bias);
@@ -832,11 +881,12 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     for (const ColSeg& s : op.segs) {
         const TensorSpec& tw = w_override ? *w_override : h->tensors[s.w];   // [ks, ks, cin, cout] (or [1,1,cin,cout])
         const int cin = (int)op.chan_map.size();
+        const int wcols = w_override ? s.cout : (int)tw.shape.back();
         for (int t = 0; t < taps; ++t)
             for (int ci = 0; ci < cin; ++ci) {
                 const int kp = op.chan_map[ci];
                 const int chunk = kp / kc, kk = kp % kc;
-                const float* wrow = &tw.data[((size_t)t * cin + ci) * s.cout];
+                const float* wrow = &tw.data[((size_t)t * cin + ci) * wcols + s.col0];
                 for (int co = 0; co < s.cout; ++co) {
                     const int cc = s.dst + co;
                     const int tile = cc / (nt * 16), j = cc % (nt * 16);
@@ -845,8 +895,8 @@ int finalize_op(dcscn_ctx* h, Op& op) {
             }
         for (int co = 0; co < s.cout; ++co) {
             if (op.fold_s > 0) bias[s.dst + co] = derived_bias[co];
-            else if (s.b >= 0) bias[s.dst + co] = h->tensors[s.b].data[co];
-            alpha[s.dst + co] = s.alpha >= 0 ? h->tensors[s.alpha].data[co] : op.const_alpha;
+            else if (s.b >= 0) bias[s.dst + co] = h->tensors[s.b].data[s.col0 + co];
+            alpha[s.dst + co] = s.alpha >= 0 ? h->tensors[s.alpha].data[s.col0 + co] : op.const_alpha;
         }
     }
     int rc = upload(h, pack.data(), pack.size() * sizeof(float), (void**)&op.d_w);
@@ -968,7 +1018,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     a.dww = op.d_dww;
     a.dwk = op.dwk;
     a.fold = op.fold_s > 0 ? 1 : 0;
-    if (op.shape.wino) HIP_TRY(h, wino_launch(op.shape.nt, a, op.n_tiles, stream));
+    if (op.shape.wino) HIP_TRY(h, wino_launch(op.shape.nt, op.shape.kc, a, op.n_tiles, stream));
     else HIP_TRY(h, conv_launch(op.shape, a, op.n_tiles, stream));
     return DCSCN_OK;
 }
@@ -1320,6 +1370,7 @@ int dcscn_finalize(dcscn_handle h) {
         if (!t.set) return fail(h, DCSCN_ERR_MISSING_TENSOR, "variable '%s' was never set", t.name.c_str());
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->fold_tail) fold_linear_tail(h);      // silently keeps the layer-by-layer graph where it does not apply
+    split_wino_tails(h);
     for (Op& op : h->ops) {
         int rc = finalize_op(h, op);
         if (rc) return rc;

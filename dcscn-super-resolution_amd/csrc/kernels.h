@@ -90,7 +90,8 @@ __host__ __device__ constexpr int wino_lds_ns(int nt) { return kWinoBVec ? 16 * 
 __host__ __device__ constexpr int wino_glb_ns(int nt) { return kWinoBVec ? 16 * nt : conv_ns(nt); }
 // column of output channel jn (0 .. 16 nt - 1 within its group) inside a global (f, kk) row
 __host__ __device__ constexpr int wino_glb_col(int nt, int jn) { return kWinoBVec ? (jn % 16) * nt + jn / 16 : jn; }
-hipError_t wino_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
+constexpr int kWinoTailKC = 8;   // K chunk of the dedicated kernel for a layer's 1-tile tail group (api.hip: split_wino_tails)
+hipError_t wino_launch(int nt, int kc, const ConvArgs& a, int n_groups, hipStream_t stream);
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
 int conv_max_fused_dw_nt();
 

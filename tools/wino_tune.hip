@@ -237,10 +237,19 @@ int main(int argc, char** argv) {
     const Layer cnn8{"CNN8", 97, 86, 1316, 984, 1316, 1084};
     const Layer cnn12{"CNN12", 57, 48, 1316, 1248, 1316, 1268};
     const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
-    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);
-    run<2, 11, 3, 4, 2, false, 7, 4, false, 0, 3>(cnn2);
-    run<2, 11, 3, 4, 2, true, 0, 4, false, 0, 3>(cnn2);
-    run<2, 11, 2, 4, 2, true, 0, 4, false, 0, 3, true>(cnn2);
-    run<2, 8, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn5);
+    const Layer tail1{"tail16", 166, 16, 1316, 196, 1316, 364};
+    const Layer tail2{"tail32", 166, 32, 1316, 196, 1316, 364};
+    const Layer full3{"full48", 166, 48, 1316, 196, 1316, 364};
+    run<4, 1, 3, 4, 2, false, 0, 4, false, 0, 3>(tail1);
+    run<4, 1, 1, 4, 4, false, 0, 4, false, 0, 3>(tail1);
+    run<4, 1, 1, 8, 4, false, 0, 4, false, 0, 3>(tail1);
+    run<4, 1, 1, 8, 3, false, 0, 4, false, 0, 3>(tail1);
+    run<4, 1, 1, 16, 3, false, 0, 4, false, 0, 3>(tail1);
+    run<4, 1, 1, 16, 2, false, 0, 4, false, 0, 3>(tail1);
+    run<4, 2, 3, 4, 2, false, 0, 4, false, 0, 3>(tail2);
+    run<4, 2, 2, 8, 2, false, 0, 4, false, 0, 3>(tail2);
+    run<4, 2, 2, 16, 2, false, 0, 4, false, 0, 3>(tail2);
+    run<4, 3, 3, 4, 2, false, 0, 4, false, 0, 3>(full3);
+    run<4, 3, 3, 8, 2, false, 0, 4, false, 0, 3>(full3);
     return 0;
 }
