@@ -1508,6 +1508,18 @@ int dcscn_forward(dcscn_handle h, const float* x, const float* x2, float* y, int
     return DCSCN_OK;
 }
 
+int dcscn_resample_table(int in_size, int out_size, int* ksize, int* bounds, double* weights, int capacity) {
+    if (in_size <= 0 || out_size <= 0 || !ksize) return DCSCN_ERR_INVALID_ARG;
+    std::vector<int> b;
+    std::vector<double> k;
+    *ksize = resample_coeffs(in_size, out_size, &b, &k);
+    if (!bounds && !weights) return DCSCN_OK;                       // size query
+    if (!bounds || !weights || capacity < (int)k.size()) return DCSCN_ERR_INVALID_ARG;
+    std::copy(b.begin(), b.end(), bounds);
+    std::copy(k.begin(), k.end(), weights);
+    return DCSCN_OK;
+}
+
 int dcscn_resize_bicubic(dcscn_handle h, const float* in, float* out, int n, int height, int width, int out_height, int out_width) {
     if (!h) return DCSCN_ERR_INVALID_ARG;
     if (n < 0 || height <= 0 || width <= 0 || out_height <= 0 || out_width <= 0)

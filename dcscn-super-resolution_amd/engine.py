@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "dcscn_layer_info_get", "dcscn_num_ops", "dcscn_op_info_get", "dcscn_set_option", "dcscn_forward",
     "dcscn_forward_device", "dcscn_forward_ensemble", "dcscn_get_profile", "dcscn_workspace_bytes",
     "dcscn_last_error", "dcscn_destroy", "dcscn_resize_bicubic", "dcscn_resize_bicubic_device", "dcscn_forward_lr",
+    "dcscn_resample_table",
 )
 
 
@@ -135,6 +136,7 @@ def load_library():
     lib.dcscn_resize_bicubic.argtypes = [vp, fp, fp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int]
     lib.dcscn_resize_bicubic_device.argtypes = [vp, vp, vp, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int, vp]
     lib.dcscn_forward_lr.argtypes = [vp, fp, fp, c.c_int, c.c_int, c.c_int]
+    lib.dcscn_resample_table.argtypes = [c.c_int, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), dp, c.c_int]
     lib.dcscn_get_profile.argtypes = [vp, dp, c.c_int]
     lib.dcscn_workspace_bytes.argtypes = [vp]
     lib.dcscn_workspace_bytes.restype = c.c_int64
@@ -187,6 +189,24 @@ def make_config(cfg):
     c.legacy_no_c = int(bool(get("legacy_no_c", False)))
     c.batch_norm = int(bool(get("batch_norm", False)))
     return c
+
+
+def resample_table(in_size, out_size):
+    """(bounds [out, 2] int32, weights [out, ksize] float64) of the Pillow-compatible bicubic resize along one
+    axis (dcscn_resample_table); host code of the library, needs no GPU."""
+    lib = load_library()
+    ks = ctypes.c_int(0)
+    rc = lib.dcscn_resample_table(int(in_size), int(out_size), ctypes.byref(ks), None, None, 0)
+    if rc:
+        raise EngineError(rc, "dcscn_resample_table(%d, %d)" % (in_size, out_size))
+    bounds = np.zeros((int(out_size), 2), np.int32)
+    weights = np.zeros((int(out_size), ks.value), np.float64)
+    rc = lib.dcscn_resample_table(int(in_size), int(out_size), ctypes.byref(ks),
+                                  bounds.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                  weights.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), weights.size)
+    if rc:
+        raise EngineError(rc, "dcscn_resample_table(%d, %d)" % (in_size, out_size))
+    return bounds, weights
 
 
 class Engine:

@@ -170,6 +170,11 @@ int dcscn_forward(dcscn_handle h, const float* x, const float* x2, float* y, int
  * hipStream_t (NULL = the handle's stream) and does not synchronise.  Usable before dcscn_finalize. */
 int dcscn_resize_bicubic(dcscn_handle h, const float* in, float* out, int n, int height, int width,
                          int out_height, int out_width);
+/* The per-axis tables the resize uses (Pillow's precompute_coeffs for BICUBIC over the whole axis): for output
+ * index i, `bounds[2i]` = first input index, `bounds[2i+1]` = taps, `weights[i * ksize + t]` = normalised float64
+ * weight of tap t.  Host only, needs no device.  Call with bounds = weights = NULL to get `ksize`; `capacity` is
+ * the number of doubles `weights` can hold (>= out_size * ksize). */
+int dcscn_resample_table(int in_size, int out_size, int* ksize, int* bounds, double* weights, int capacity);
 int dcscn_resize_bicubic_device(dcscn_handle h, const float* in, float* out, int n, int height, int width,
                                 int out_height, int out_width, void* stream);
 

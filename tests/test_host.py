@@ -243,3 +243,29 @@ def test_no_cpu_fallback():
     src = open(os.path.join(ROOT, "dcscn-super-resolution_amd", "model.py")).read() + \
         open(os.path.join(ROOT, "dcscn-super-resolution_amd", "engine.py")).read()
     assert "oracle" not in src
+
+
+def test_resample_tables_reproduce_pillow():
+    """The library's per-axis bicubic tables (host code, no GPU), applied in float64 in tap order with one rounding
+    per pass, must give Pillow's mode-'F' BICUBIC resize bit for bit -- the same tables drive the device kernels
+    (tests/test_resize_hip.py checks those against Pillow on the GPU)."""
+    from PIL import Image
+    from dcscn_amd import engine
+
+    def one_axis(img, out):                       # resize axis 1 of [rows, n] float32
+        bounds, w = engine.resample_table(img.shape[1], out)
+        res = np.zeros((img.shape[0], out), np.float32)
+        for i in range(out):
+            x0, n = bounds[i]
+            ss = np.zeros(img.shape[0])
+            for t in range(n):
+                ss = ss + img[:, x0 + t].astype(np.float64) * w[i, t]
+            res[:, i] = ss.astype(np.float32)
+        return res
+
+    rng = np.random.default_rng(0)
+    for (h, w), (oh, ow) in [((12, 14), (36, 42)), ((31, 17), (62, 34)), ((40, 36), (10, 9)), ((9, 20), (27, 5))]:
+        img = rng.uniform(0, 255, (h, w)).astype(np.float32)
+        ref = np.asarray(Image.fromarray(img).resize([ow, oh], resample=Image.BICUBIC))
+        got = one_axis(one_axis(img, ow).T.copy(), oh).T          # horizontal pass first, as Pillow
+        assert np.array_equal(got, ref)

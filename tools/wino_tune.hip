@@ -237,19 +237,12 @@ int main(int argc, char** argv) {
     const Layer cnn8{"CNN8", 97, 86, 1316, 984, 1316, 1084};
     const Layer cnn12{"CNN12", 57, 48, 1316, 1248, 1316, 1268};
     const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
-    const Layer tail1{"tail16", 166, 16, 1316, 196, 1316, 364};
-    const Layer tail2{"tail32", 166, 32, 1316, 196, 1316, 364};
-    const Layer full3{"full48", 166, 48, 1316, 196, 1316, 364};
-    run<4, 1, 3, 4, 2, false, 0, 4, false, 0, 3>(tail1);
-    run<4, 1, 1, 4, 4, false, 0, 4, false, 0, 3>(tail1);
-    run<4, 1, 1, 8, 4, false, 0, 4, false, 0, 3>(tail1);
-    run<4, 1, 1, 8, 3, false, 0, 4, false, 0, 3>(tail1);
-    run<4, 1, 1, 16, 3, false, 0, 4, false, 0, 3>(tail1);
-    run<4, 1, 1, 16, 2, false, 0, 4, false, 0, 3>(tail1);
-    run<4, 2, 3, 4, 2, false, 0, 4, false, 0, 3>(tail2);
-    run<4, 2, 2, 8, 2, false, 0, 4, false, 0, 3>(tail2);
-    run<4, 2, 2, 16, 2, false, 0, 4, false, 0, 3>(tail2);
-    run<4, 3, 3, 4, 2, false, 0, 4, false, 0, 3>(full3);
-    run<4, 3, 3, 8, 2, false, 0, 4, false, 0, 3>(full3);
+    const Layer wide{"wide192", 196, 192, 1316, 0, 1316, 196};
+    run<2, 12, 3, 4, 2, false, 0, 4, false, 0, 3>(wide);              // shipped kernel: 4 groups of 3 tiles
+    run<2, 12, 6, 4, 1, false, 0, 4, false, 0, 3>(wide);              // 6 tiles, one wave per SIMD, plain loop
+    run<2, 12, 6, 4, 1, true, 0, 4, false, 0, 3>(wide);               // + staging inside the MFMA stream
+    run<2, 12, 6, 4, 1, true, 0, 4, false, 0, 3, true>(wide);         // + next chunk's raw read / transform hidden
+    run<2, 12, 6, 4, 1, true, 0, 4, false, 0, 4, true>(wide);
+    run<2, 12, 4, 4, 1, true, 0, 4, false, 0, 3, true>(wide);         // 4 tiles per group (3 groups)
     return 0;
 }
