@@ -449,15 +449,17 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
             float dn[4][4], vn[16];
             mfma_step(cur + b_lane, v, [&](auto f_) DCSCN_INL {
                 constexpr int F = decltype(f_)::value;
-                if constexpr (F == 3) {
+                // ABLATE 21 / 22 / 23 (tuner only): no staging / no raw read + transform / neither
+                if constexpr (F == 3 && ABLATE != 21 && ABLATE != 23) {
                     store_b(nxt);                          // filters c+1
                     store_a(cur, clamp(chunk + 2));        // input c+2 over input c (read during chunk c-1)
                     load_b(clamp(chunk + 2));
                     load_a(clamp(chunk + 3));
-                } else if constexpr (F == 7) {
+                } else if constexpr (F == 7 && ABLATE != 22 && ABLATE != 23) {
                     read_raw(nxt + a_lane, dn);
                 } else if constexpr (F == 11) {
-                    transform(dn, vn);
+                    if constexpr (ABLATE != 22 && ABLATE != 23) transform(dn, vn);
+                    else static_for<0, 16>([&](auto g_) DCSCN_INL { vn[decltype(g_)::value] = v[decltype(g_)::value]; });
                 }
             });
             __syncthreads();
