@@ -601,13 +601,13 @@ int op_tiles16(const Op& op) {
 
 // Winograd F(2x2,3x3) for 3x3 convs with enough input channels to amortise the transforms (measured on MI355X:
 // 1.25-1.35x over conv_igemm from 57 input channels up; the tiny layers of the c-DCSCN models stay on the direct
-// kernel).  The Winograd kernel's cost follows its number of channel groups (ceil(tiles / 3)), not its MFMA count:
-// with 4 tiles of 16 (3 + 1) the direct kernel wins (CNN11 66->57: 1.37 vs 1.49 ms), and a single tile gains
-// nothing.  (op.vec4: the Winograd epilogue only has the 16-byte store form.)
+// kernel).  The Winograd kernel's cost follows its number of channel groups (ceil(tiles / 3)), not its MFMA count;
+// a 3k+1-tile layer gets its last tile from split_wino_tails (before that existed, 4 tiles = 3 + 1 were faster on
+// the direct kernel: CNN11 66->57 1.37 vs 1.49 ms).  (op.vec4: the Winograd epilogue only has the 16-byte store form.)
 bool wino_eligible(const dcscn_ctx* h, const Op& op) {
     const int tiles16 = op_tiles16(op);
     return h->winograd && op.kind == OP_CONV && op.vec4 && op.ks == 3 && op.dwk == 0 && op.cin_phys >= 32 &&
-           op.segs.size() == 1 && op.tconv_s == 0 && tiles16 >= 2 && tiles16 != 4;
+           op.segs.size() == 1 && op.tconv_s == 0 && tiles16 >= 2;
 }
 
 // A layer whose 16-channel tiles do not fill groups of 3 ends in a 1-tile group that costs almost as much as a
@@ -618,7 +618,7 @@ void split_wino_tails(dcscn_ctx* h) {
     std::vector<Op> out;
     for (const Op& op : h->ops) {
         const int tiles16 = op_tiles16(op);
-        if (!wino_eligible(h, op) || tiles16 < 7 || tiles16 % 3 != 1 || op.ps != 1 || op.fold_s > 0 || op.segs[0].dst != 0) {
+        if (!wino_eligible(h, op) || tiles16 < 4 || tiles16 % 3 != 1 || op.ps != 1 || op.fold_s > 0 || op.segs[0].dst != 0) {
             out.push_back(op);
             continue;
         }

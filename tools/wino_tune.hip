@@ -357,10 +357,11 @@ int main(int argc, char** argv) {
     const Layer cnn8{"CNN8", 97, 86, 1316, 984, 1316, 1084};
     const Layer cnn12{"CNN12", 57, 48, 1316, 1248, 1316, 1268};
     const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
-    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);
-    run_fs<2, 11, 3, 2>(cnn2);
-    run<2, 8, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn5);
-    run_fs<2, 8, 3, 2>(cnn5);
-    run_fs<2, 8, 2, 2>(cnn5);
+    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);      // shipped
+    run<2, 11, 3, 4, 2, false, 9, 4, false, 0, 3>(cnn2);      // input-tile loads coalesced (wrong data)
+    run<2, 11, 3, 4, 2, false, 11, 4, false, 0, 3>(cnn2);     // + filters L1-hot
+    run<2, 11, 3, 4, 2, true, 9, 4, false, 0, 3>(cnn2);       // pipelined staging, coalesced
+    run<2, 11, 3, 4, 2, true, 11, 4, false, 0, 3>(cnn2);
+    run<2, 11, 3, 4, 2, false, 1, 4, false, 0, 3>(cnn2);      // no loads in the loop
     return 0;
 }
