@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_NAME = "libdcscn_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
-SOURCES = ["api.hip", "kernels.hip", "resample.hip", "conv_k1.hip", "conv_k3.hip", "conv_k5.hip", "conv_k7.hip", "conv_wino.hip"]
+SOURCES = ["api.hip", "kernels.hip", "resample.hip", "ensemble.hip", "conv_k1.hip", "conv_k3.hip", "conv_k5.hip", "conv_k7.hip", "conv_wino.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "conv_igemm.hpp", "conv_wino.hpp", "conv_variants.hpp")] + \
           [os.path.join(INCLUDE, "dcscn.h")]
 ARCH = "gfx950"

@@ -137,6 +137,9 @@ struct dcscn_ctx {
     struct ResampleTable { int ksize = 0; int* d_bounds = nullptr; double* d_kk = nullptr; };
     std::map<std::pair<int, int>, ResampleTable> resample_tables;
     float* rs_tmp = nullptr; size_t rs_tmp_cap = 0;
+    // self-ensemble (ensemble.hip): flipped copies, their outputs, float64 mean (as 2 floats per double)
+    float* ens_x = nullptr; float* ens_x2 = nullptr; float* ens_y = nullptr; float* ens_out = nullptr;
+    size_t ens_x_cap = 0, ens_x2_cap = 0, ens_y_cap = 0, ens_out_cap = 0;
     float* rs_in = nullptr; float* rs_out = nullptr; size_t rs_in_cap = 0, rs_out_cap = 0;
     // spatial tiling of images larger than one pass (run_tiled): gathered tile batch
     float* tile_x = nullptr; float* tile_x2 = nullptr; float* tile_y = nullptr;
@@ -1225,20 +1228,6 @@ int resize_device(dcscn_ctx* h, const float* in, float* out, int n, int H, int W
     return DCSCN_OK;
 }
 
-// flip / rotate index maps of helper/utilty.py:595-617: transformed[r][c] = image[src_r][src_c]
-inline void flip_src(int type, int h, int w, int r, int c, int* sr, int* sc) {
-    switch (type) {
-        case 0: *sr = r; *sc = c; break;
-        case 1: *sr = h - 1 - r; *sc = c; break;                // flipud
-        case 2: *sr = r; *sc = w - 1 - c; break;                // fliplr
-        case 3: *sr = h - 1 - r; *sc = w - 1 - c; break;        // flipud(fliplr)
-        case 4: *sr = c; *sc = w - 1 - r; break;                // rot90(+1): shape [w, h]
-        case 5: *sr = h - 1 - c; *sc = r; break;                // rot90(-1)
-        case 6: *sr = c; *sc = r; break;                        // flipud(rot90(+1)) = transpose
-        default: *sr = h - 1 - c; *sc = w - 1 - r; break;       // flipud(rot90(-1)) = anti-transpose
-    }
-}
-
 }  // namespace
 
 // ================================================================================================
@@ -1572,54 +1561,35 @@ int dcscn_forward_lr(dcscn_handle h, const float* x, float* y, int n, int height
 
 int dcscn_forward_ensemble(dcscn_handle h, const float* x, const float* x2, double* y, int height, int width, int n_ensemble) {
     if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_forward_ensemble before dcscn_finalize");
     if (!x || !x2 || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
     if (n_ensemble < 1 || n_ensemble > 8) return fail(h, DCSCN_ERR_INVALID_ARG, "n_ensemble %d outside [1, 8]", n_ensemble);
     if (height <= 0 || width <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape h=%d w=%d", height, width);
-    const int s = h->cfg.scale;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int s = h->cfg.scale, n = n_ensemble;
     const size_t lr = (size_t)height * width, hr = lr * s * s;
-    const int na = std::min(n_ensemble, 4), nb = n_ensemble - na;   // types 0-3 keep [h, w]; 4-7 are [w, h]
-    std::vector<float> xin((size_t)n_ensemble * lr), x2in((size_t)n_ensemble * hr), yout((size_t)n_ensemble * hr);
-    for (int t = 0; t < n_ensemble; ++t) {
-        const bool rot = t >= 4;
-        const int th = rot ? width : height, tw = rot ? height : width;
-        float* xd = &xin[(size_t)t * lr];
-        float* x2d = &x2in[(size_t)t * hr];
-        for (int r = 0; r < th; ++r)
-            for (int c = 0; c < tw; ++c) {
-                int sr, sc;
-                flip_src(t, height, width, r, c, &sr, &sc);
-                xd[(size_t)r * tw + c] = x[(size_t)sr * width + sc];
-            }
-        const int Th = th * s, Tw = tw * s, Hh = height * s, Ww = width * s;
-        for (int r = 0; r < Th; ++r)
-            for (int c = 0; c < Tw; ++c) {
-                int sr, sc;
-                flip_src(t, Hh, Ww, r, c, &sr, &sc);
-                x2d[(size_t)r * Tw + c] = x2[(size_t)sr * Ww + sc];
-            }
-    }
-    int rc = dcscn_forward(h, xin.data(), x2in.data(), yout.data(), na, height, width);
+    const int na = std::min(n, 4), nb = n - na;               // types 0-3 keep [h, w]; 4-7 are [w, h]
+    // device buffers: the image pair, its n flipped copies, their outputs, the float64 mean
+    int rc = ensure_io(h, lr, hr);
+    if (!rc) rc = grow(h, &h->ens_x, &h->ens_x_cap, n * lr, h->stream);
+    if (!rc) rc = grow(h, &h->ens_x2, &h->ens_x2_cap, n * hr, h->stream);
+    if (!rc) rc = grow(h, &h->ens_y, &h->ens_y_cap, n * hr, h->stream);
+    if (!rc) rc = grow(h, &h->ens_out, &h->ens_out_cap, 2 * hr, h->stream);     // doubles
     if (rc) return rc;
-    if (nb > 0) {
-        rc = dcscn_forward(h, &xin[4 * lr], &x2in[4 * hr], &yout[4 * hr], nb, width, height);
-        if (rc) return rc;
-    }
-    // output = zeros; output += restored_i (i ascending); output /= n   (DCSCN.py:560-573), float64
-    for (size_t i = 0; i < hr; ++i) y[i] = 0.0;
-    const int Hh = height * s, Ww = width * s;
-    for (int t = 0; t < n_ensemble; ++t) {
-        const bool rot = t >= 4;
-        const int Th = (rot ? width : height) * s, Tw = (rot ? height : width) * s;
-        const float* yt = &yout[(size_t)t * hr];
-        for (int r = 0; r < Th; ++r)
-            for (int c = 0; c < Tw; ++c) {
-                int sr, sc;
-                flip_src(t, Hh, Ww, r, c, &sr, &sc);
-                y[(size_t)sr * Ww + sc] += (double)yt[(size_t)r * Tw + c];
-            }
-    }
-    if (n_ensemble > 1)
-        for (size_t i = 0; i < hr; ++i) y[i] /= (double)n_ensemble;
+    HIP_TRY(h, hipMemcpy(h->io_x, x, lr * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->io_x2, x2, hr * sizeof(float), hipMemcpyHostToDevice));
+    // util.flip(image, i) for i < n (DCSCN.py:562-564), on the device
+    HIP_TRY(h, ensemble_gather_launch(h->io_x, h->ens_x, height, width, n, h->stream));
+    HIP_TRY(h, ensemble_gather_launch(h->io_x2, h->ens_x2, height * s, width * s, n, h->stream));
+    // two batches: the reference runs n forwards of batch 1 (DCSCN.py:565-569)
+    rc = run_forward(h, h->ens_x, h->ens_x2, h->ens_y, na, height, width, h->stream);
+    if (!rc && nb > 0)
+        rc = run_forward(h, h->ens_x + (size_t)na * lr, h->ens_x2 + (size_t)na * hr, h->ens_y + (size_t)na * hr, nb, width, height, h->stream);
+    if (rc) return rc;
+    // output = zeros(float64); output += flip(y_i, invert=True) for i ascending; output /= n  (DCSCN.py:560-573)
+    HIP_TRY(h, ensemble_reduce_launch(h->ens_y, reinterpret_cast<double*>(h->ens_out), height * s, width * s, n, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(y, h->ens_out, hr * sizeof(double), hipMemcpyDeviceToHost));
     return DCSCN_OK;
 }
 
@@ -1657,7 +1627,7 @@ int dcscn_destroy(dcscn_handle h) {
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (void* p : h->device_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
-    for (float* p : {h->tile_x, h->tile_x2, h->tile_y, h->rs_tmp, h->rs_in, h->rs_out})
+    for (float* p : {h->tile_x, h->tile_x2, h->tile_y, h->rs_tmp, h->rs_in, h->rs_out, h->ens_x, h->ens_x2, h->ens_y, h->ens_out})
         if (p) (void)hipFree(p);
     if (h->io_x) (void)hipFree(h->io_x);
     if (h->io_x2) (void)hipFree(h->io_x2);

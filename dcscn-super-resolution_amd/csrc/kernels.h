@@ -95,6 +95,10 @@ hipError_t wino_launch(int nt, int kc, const ConvArgs& a, int n_groups, hipStrea
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
 int conv_max_fused_dw_nt();
 
+// self-ensemble gather / float64 reduce (ensemble.hip); images of one call all have h*w pixels, types 4-7 transposed
+hipError_t ensemble_gather_launch(const float* in, float* out, int h, int w, int n, hipStream_t stream);
+hipError_t ensemble_reduce_launch(const float* y, double* out, int h, int w, int n, hipStream_t stream);
+
 // Pillow-compatible bicubic resize of 1-channel float images (resample.hip)
 int resample_coeffs(int in_size, int out_size, std::vector<int>* bounds, std::vector<double>* kk);   // returns ksize
 hipError_t resample_h_launch(const float* in, float* out, const int* bounds, const double* kk, int ksize,
