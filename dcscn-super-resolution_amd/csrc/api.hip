@@ -67,6 +67,8 @@ struct ColSeg {
     int cout = 0;                     // output channels taken from the tensors ...
     int col0 = 0;                     // ... starting at this one (a layer split over two launches)
     int dst = 0;
+    int dw1 = -1;                     // 1x1 depthwise filter [1, 1, cin, 1] of a separable 1x1 conv, folded into the
+                                      // pointwise weights when they are packed: sum_c (x_c d_c) p_co = sum_c x_c (d_c p_co)
 };
 
 struct Op {
@@ -286,6 +288,14 @@ void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_nam
     if (bias) seg.b = add_tensor(h, var + "/conv_B", {cout});
     if (activator == DCSCN_ACT_PRELU) seg.alpha = add_tensor(h, var + "/prelu/" + short_name + "_prelu", {cout});
 
+    // A separable conv with a 1x1 depthwise half (A1 / B1 of the DS models, tf_graph.py:155-177) is a plain 1x1 conv
+    // whose weights carry the per-channel scale: no depthwise stage at all, and A1 / B1 can share one launch.
+    const bool fold_dw1 = ds && ks == 1 && src.buf >= 0;
+    if (fold_dw1) {
+        seg.dw1 = t_dw;
+        ds = false;
+    }
+
     Op op;
     op.name = var;
     op.res = src.res;
@@ -488,7 +498,7 @@ int build_graph(dcscn_ctx* h) {
         db.buf = t1; db.off = 0; db.width = pad4(nb);
         add_conv(h, "A1", "A1", cat, 1, na, true, c.activator, ds, da, &dw_buf);
         add_conv(h, "B1", "B1", cat, 1, nb, true, c.activator, ds, db, &dw_buf);
-        if (!ds) {
+        {
             // A1 and B1 read the same 1301-wide concat: run them as ONE GEMM with conv channels
             // [B1 | pad to 16 | A1] and two destinations (halves the concat traffic).
             Op b1 = h->ops.back();
@@ -890,10 +900,12 @@ int finalize_op(dcscn_ctx* h, Op& op) {
                 const int kp = op.chan_map[ci];
                 const int chunk = kp / kc, kk = kp % kc;
                 const float* wrow = &tw.data[((size_t)t * cin + ci) * wcols + s.col0];
+                const float dscale = s.dw1 >= 0 ? h->tensors[s.dw1].data[ci] : 1.0f;     // folded 1x1 depthwise
                 for (int co = 0; co < s.cout; ++co) {
                     const int cc = s.dst + co;
                     const int tile = cc / (nt * 16), j = cc % (nt * 16);
-                    pack[((size_t)tile * op.n_chunks + chunk) * chunk_floats + ((size_t)t * kc + kk) * ns + j] = wrow[co];
+                    pack[((size_t)tile * op.n_chunks + chunk) * chunk_floats + ((size_t)t * kc + kk) * ns + j] =
+                        s.dw1 >= 0 ? dscale * wrow[co] : wrow[co];
                 }
             }
         for (int co = 0; co < s.cout; ++co) {
