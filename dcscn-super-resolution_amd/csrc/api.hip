@@ -327,7 +327,7 @@ void add_conv(dcscn_ctx* h, const std::string& var, const std::string& short_nam
         op.dw_w = t_dw;
         op.macs = li.macs_per_lr_pixel;
         op.bytes = 4 * r2 * src.cin_phys + out_bytes + (dst.residual ? 4 * r2 : 0);
-    } else if (ds && src.buf >= 0 && ks <= 3) {
+    } else if (ds && src.buf >= 0 && ks == 3) {
         // depthwise half fused into the staging of the pointwise GEMM: its output never touches HBM
         // (instantiated for 1x1 / 3x3 depthwise filters; --cnn_size=5/7 separable models take the two-launch form below)
         op.kind = OP_CONV;

@@ -9,8 +9,7 @@ hipError_t conv_init_k1() {
     DCSCN_FOR_NT(X, 1)
 #undef X
 #define X(KS, NT, DWK) if ((e = Variant<KS, NT, DWK>::set_attr()) != hipSuccess) return e;
-    DCSCN_FOR_NT_DW(X, 1)
-    DCSCN_FOR_NT_DW(X, 3)
+    DCSCN_FOR_NT_DW(X, 3)      // 1x1 depthwise halves are folded into the pointwise weights (api.hip: ColSeg::dw1)
 #undef X
     return hipSuccess;
 }
@@ -19,7 +18,6 @@ hipError_t conv_launch_k1(int nt, int dwk, const ConvArgs& a, int n_tiles, hipSt
     if (dwk != 0) {
         switch (dwk * 100 + nt) {
 #define X(KS, NT, DWK) case DWK * 100 + NT: return Variant<KS, NT, DWK>::launch(a, n_tiles, stream);
-            DCSCN_FOR_NT_DW(X, 1)
             DCSCN_FOR_NT_DW(X, 3)
 #undef X
             default: return hipErrorInvalidValue;

@@ -22,12 +22,14 @@ __host__ __device__ constexpr int pick_wps(int ks, int nt) {
 }
 constexpr bool kDoubleBuffer = false;
 
-inline size_t lds_bytes_for(int ks, int mt, int nt, int kc) {
+inline size_t lds_bytes_for(int ks, int mt, int nt, int kc, int dwk = 0) {
     const int halo = ks / 2;
     const int hp = (4 * mt + 2 * halo) * (16 + 2 * halo);
     const int ps = conv_plane_stride(hp);
     const int ns = conv_ns(nt);
-    return (kDoubleBuffer ? 2 : 1) * (size_t)(kc * ps + ks * ks * kc * ns) * sizeof(float);
+    size_t floats = (kDoubleBuffer ? 2 : 1) * (size_t)(kc * ps + ks * ks * kc * ns);
+    if (dwk > 0) floats += (size_t)kc * conv_plane_stride((4 * mt + dwk - 1) * (16 + dwk - 1)) + (size_t)dwk * dwk * kc;   // DwGeom
+    return floats * sizeof(float);
 }
 
 #define DCSCN_FOR_NT(X, KS) \
@@ -41,7 +43,7 @@ template <int KS, int NT, int DWK = 0>
 struct Variant {
     static constexpr int MT = pick_mt(KS, NT), KC = pick_kc(KS, NT), WPS = pick_wps(KS, NT);
     static constexpr auto kernel = &conv_igemm<KS, MT, NT, KC, kDoubleBuffer, WPS, DWK>;
-    static size_t lds() { return lds_bytes_for(KS, MT, NT, KC); }
+    static size_t lds() { return lds_bytes_for(KS, MT, NT, KC, DWK); }
     static hipError_t set_attr() {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds());
     }

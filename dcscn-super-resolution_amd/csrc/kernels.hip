@@ -17,7 +17,7 @@ namespace dcscn {
 
 // ---- dispatch over the per-family translation units (conv_k1.hip, conv_k3.hip, conv_wino.hip) --------
 ConvShape conv_pick_shape(int ks, int nt, int dwk) { return ConvShape{ks, pick_mt(ks, nt), nt, pick_kc(ks, nt), dwk}; }
-size_t conv_lds_bytes(const ConvShape& s) { return lds_bytes_for(s.ks, s.mt, s.nt, s.kc); }
+size_t conv_lds_bytes(const ConvShape& s) { return lds_bytes_for(s.ks, s.mt, s.nt, s.kc, s.dwk); }
 int conv_max_fused_dw_nt() { return kMaxDwNt; }
 int conv_max_nt(int ks) { return ks == 7 ? kMaxK7Nt : 13; }
 
