@@ -833,7 +833,7 @@ int finalize_op(dcscn_ctx* h, Op& op) {
         op.ctot = op.n_tiles * nt * 16;
         const int kc = op.shape.kc;
         op.n_chunks = (op.cin_phys + kc - 1) / kc;
-        const int ns = wino_glb_ns(nt);
+        const int ns = conv_ns(nt);
         const size_t chunk_floats = (size_t)16 * kc * ns;
         // + one staging sweep of slack: the kernel loads the last partial sweep of a chunk with every
         // thread (only the LDS store is predicated), which may run past the final chunk by < 2048 floats
@@ -858,7 +858,7 @@ int finalize_op(dcscn_ctx* h, Op& op) {
                 for (int xi = 0; xi < 4; ++xi)
                     for (int nu = 0; nu < 4; ++nu) {                // (G g) G^T, float64, rounded once
                         const double u = gg[xi][0] * G[nu][0] + gg[xi][1] * G[nu][1] + gg[xi][2] * G[nu][2];
-                        pack[((size_t)tile * op.n_chunks + chunk) * chunk_floats + ((size_t)(xi * 4 + nu) * kc + kk) * ns + wino_glb_col(nt, jn)] = (float)u;
+                        pack[((size_t)tile * op.n_chunks + chunk) * chunk_floats + ((size_t)(xi * 4 + nu) * kc + kk) * ns + jn] = (float)u;
                     }
             }
         }

@@ -9,7 +9,7 @@ static hipError_t wino_launch_one(const ConvArgs& a, int n_groups, hipStream_t s
     const size_t lds = (size_t)G::BUF * sizeof(float);
     const dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x), (unsigned)n_groups);
     // single LDS buffer, 4 waves, filter reads software-pipelined three frequencies ahead (tools/wino_tune.hip)
-    hipLaunchKernelGGL((conv_wino<NT, KC, WPS, false, 0, 4, false, 0, 3>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_wino<NT, KC, WPS>), grid, dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -72,24 +72,10 @@ size_t conv_lds_bytes(const ConvShape& s);
 hipError_t conv_init_kernels();
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream);
 // Winograd F(2x2,3x3) variant of a 3x3 conv: `nt` channel tiles of 16 per group (1..3), `n_groups` groups,
-// args.nt_last = tiles in the last group, args.wpack in the [group][chunk][16 f][kk][wino_glb_ns] image.
+// args.nt_last = tiles in the last group, args.wpack in the [group][chunk][16 f][kk][conv_ns(nt)] image.
 constexpr int kWinoKC = 4;
 constexpr int kWinoMaxNT = 3;
-// Filter image of the Winograd kernel.  Per (group, chunk): [16 f][kk][16 j][nt] floats in global memory
-// (compact), [16 f][kk][16 j][npad] in LDS -- the `nt` channel tiles of one (f, kk, j) sit side by side,
-// so a lane fetches the A operands of its nt MFMAs of one frequency with ONE ds_read (b32/b64/b96)
-// instead of nt ds_read_b32.  npad = 4 for nt = 3 keeps the 16-byte alignment and makes the (kk) row
-// stride 64 floats = conflict free for the b64/b96/b128 lane groups.
-#ifndef DCSCN_WINO_BVEC
-#define DCSCN_WINO_BVEC 0
-#endif
-constexpr bool kWinoBVec = DCSCN_WINO_BVEC != 0;
-__host__ __device__ constexpr int wino_npad(int nt) { return nt == 3 ? 4 : nt; }
-// floats per (f, kk) row: in LDS / in the global image
-__host__ __device__ constexpr int wino_lds_ns(int nt) { return kWinoBVec ? 16 * wino_npad(nt) : conv_ns(nt); }
-__host__ __device__ constexpr int wino_glb_ns(int nt) { return kWinoBVec ? 16 * nt : conv_ns(nt); }
-// column of output channel jn (0 .. 16 nt - 1 within its group) inside a global (f, kk) row
-__host__ __device__ constexpr int wino_glb_col(int nt, int jn) { return kWinoBVec ? (jn % 16) * nt + jn / 16 : jn; }
+// Filter image of the Winograd kernel: [group][chunk][16 f][kk][conv_ns(nt)], the exact LDS image of a chunk.
 constexpr int kWinoTailKC = 8;   // K chunk of the dedicated kernel for a layer's 1-tile tail group (api.hip: split_wino_tails)
 hipError_t wino_launch(int nt, int kc, const ConvArgs& a, int n_groups, hipStream_t stream);
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for

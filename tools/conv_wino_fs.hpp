@@ -22,9 +22,10 @@
 // Staging (input halo tile + filter block of a 4-channel chunk in one LDS buffer, register prefetch of the next
 // chunk, two barriers per chunk) is the scheme of conv_wino.
 #pragma once
-#include "../dcscn-super-resolution_amd/csrc/conv_wino.hpp"
+#include "conv_wino_lab.hpp"
 
-namespace dcscn {
+namespace dcscn_lab {
+using namespace dcscn;
 
 constexpr int kWinoFsZFloats = 4 * 4 * 2 * 64 * 4;   // exchange buffer of the epilogue: [wave][block][2][lane] float4
 
@@ -283,4 +284,4 @@ __global__ __launch_bounds__(256, WPS) void conv_wino_fs(const ConvArgs a) {
     }
 }
 
-}  // namespace dcscn
+}  // namespace dcscn_lab

@@ -8,9 +8,11 @@
 #include <cstring>
 #include <vector>
 
-#include "conv_wino_fs.hpp"
+#include "../dcscn-super-resolution_amd/csrc/conv_wino.hpp"   // the shipped kernel: dcscn::conv_wino<NT, KC, WPS>
+#include "conv_wino_fs.hpp"                                     // lab variants: dcscn_lab::...
 
 using namespace dcscn;
+namespace lab = dcscn_lab;
 
 #define CK(x)                                                                              \
     do {                                                                                   \
@@ -47,7 +49,7 @@ static std::vector<float> pack_direct(const std::vector<float>& w, int cin, int 
 
 // winograd pack: [ntile][chunk][f][kk][NS], U = G g G^T in double
 static std::vector<float> pack_wino(const std::vector<float>& w, int cin, int cout, int cin_phys, int kc, int nt, int* n_chunks, int* n_tiles, int* nt_last) {
-    const int ns = wino_glb_ns(nt);
+    const int ns = lab::wino_glb_ns(nt);
     const int tiles16 = (cout + 15) / 16;
     *n_tiles = (tiles16 + nt - 1) / nt;
     *nt_last = tiles16 - (*n_tiles - 1) * nt;
@@ -66,7 +68,7 @@ static std::vector<float> pack_wino(const std::vector<float>& w, int cin, int co
                     for (int i = 0; i < 3; ++i)
                         for (int j = 0; j < 3; ++j) u += G[xi][i] * g[i][j] * G[nu][j];
                     const int f = xi * 4 + nu;
-                    p[(((size_t)tile * *n_chunks + c / kc) * 16 + f) * kc * ns + (size_t)(c % kc) * ns + wino_glb_col(nt, jn)] = (float)u;
+                    p[(((size_t)tile * *n_chunks + c / kc) * 16 + f) * kc * ns + (size_t)(c % kc) * ns + lab::wino_glb_col(nt, jn)] = (float)u;
                 }
         }
     return p;
@@ -125,7 +127,7 @@ void run(const Layer& L) {
     }
     // winograd
     {
-        using Gw = WinoGeom<NTW, KCW, WAVES>;
+        using Gw = lab::WinoGeom<NTW, KCW, WAVES>;
         int nch, ntiles, ntlast;
         std::vector<float> p = pack_wino(w, L.cin, L.cout, cin_phys, KCW, NTW, &nch, &ntiles, &ntlast);
         CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -133,7 +135,7 @@ void run(const Layer& L) {
         a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gw::TH - 1) / Gw::TH;
         a.out0 = OutDesc{g_out, L.out_stride, L.out_off, (L.cout + 3) & ~3};
         a.out1 = a.out0;
-        auto kern = conv_wino<NTW, KCW, WPSW, DBW, ABL, WAVES, DMA, PRIO, PF, VPIPE>;
+        auto kern = lab::conv_wino<NTW, KCW, WPSW, DBW, ABL, WAVES, DMA, PRIO, PF, VPIPE>;
         if (ABL == 7) { a.act = ACT_NONE; a.alpha = reinterpret_cast<const float*>(g_dbg); CK(hipMemset(g_dbg, 0, (size_t)(1024 + 4096 * 16 + 8 * 65536) * 8)); }
         const size_t lds = ((DBW || DMA) ? 2 : 1) * (size_t)Gw::BUF * sizeof(float) * (size_t)g_lds_mul;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -245,7 +247,7 @@ void run_fs(const Layer& L) {
     }
     // winograd
     {
-        using Gw = WinoGeom<NTW, KCW, WAVES>;
+        using Gw = lab::WinoGeom<NTW, KCW, WAVES>;
         int nch, ntiles, ntlast;
         std::vector<float> p = pack_wino(w, L.cin, L.cout, cin_phys, KCW, NTW, &nch, &ntiles, &ntlast);
         CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -253,9 +255,9 @@ void run_fs(const Layer& L) {
         a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gw::TH - 1) / Gw::TH;
         a.out0 = OutDesc{g_out, L.out_stride, L.out_off, (L.cout + 3) & ~3};
         a.out1 = a.out0;
-        auto kern = conv_wino_fs<NTW, WPSW>;
+        auto kern = lab::conv_wino_fs<NTW, WPSW>;
         if (ABL == 7) { a.act = ACT_NONE; a.alpha = reinterpret_cast<const float*>(g_dbg); CK(hipMemset(g_dbg, 0, (size_t)(1024 + 4096 * 16 + 8 * 65536) * 8)); }
-        const size_t lds = wino_fs_lds_bytes<NTW>() * (size_t)g_lds_mul;
+        const size_t lds = lab::wino_fs_lds_bytes<NTW>() * (size_t)g_lds_mul;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int occ = 0;
         CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WAVES, lds));
@@ -333,6 +335,126 @@ void run_fs(const Layer& L) {
     fflush(stdout);
 }
 
+// the SHIPPED kernel (csrc/conv_wino.hpp) against the direct kernel
+template <int MT, int NTD, int NTW, int KCS, int WPSW>
+void run_shipped(const Layer& L) {
+    constexpr int KCW = KCS, WAVES = 4, ABL = 0, PRIO = 0, PF = 0;
+    constexpr bool DBW = false, DMA = false, VPIPE = false;
+    const int cin_phys = (L.cin + 3) & ~3;
+    std::vector<float> w = rand_vec((size_t)9 * L.cin * L.cout, 777, 0.2f);
+    ConvArgs a{};
+    a.in = g_in; a.in_stride = L.in_stride; a.in_off = L.in_off; a.cin_phys = cin_phys;
+    a.bias = g_bias; a.alpha = g_bias; a.act = ACT_ALPHA;
+    a.N = N; a.H = H; a.W = W;
+    a.split = 1 << 30; a.ps = 1; a.ps_c = 1; a.vec4 = 1; a.res = nullptr; a.res_stride = 1;
+    const double flop = 2.0 * 9 * L.cin * (double)L.cout * N * H * W;
+
+    // reference: direct kernel
+    {
+        using Gd = ConvGeom<3, MT, NTD, 4>;
+        int nch;
+        std::vector<float> p = pack_direct(w, L.cin, L.cout, cin_phys, 4, NTD, &nch);
+        CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+        a.wpack = g_w; a.n_chunks = nch;
+        a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gd::TH - 1) / Gd::TH;
+        a.out0 = OutDesc{g_ref, L.out_stride, L.out_off, (L.cout + 3) & ~3};
+        a.out1 = a.out0;
+        auto kern = conv_igemm<3, MT, NTD, 4, false, 3>;
+        const size_t lds = (size_t)Gd::BUF * sizeof(float);
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const float ms = time_kernel(kern, dim3(N * a.tiles_y * a.tiles_x, 1), lds, a);
+        printf("%-8s %4d->%-4d direct MT%d NT%-2d            %8.3f ms  %7.2f TFLOP/s\n", L.name, L.cin, L.cout, MT, NTD, ms, flop / (ms * 1e-3) / 1e12);
+    }
+    // winograd
+    {
+        using Gw = lab::WinoGeom<NTW, KCW, WAVES>;
+        int nch, ntiles, ntlast;
+        std::vector<float> p = pack_wino(w, L.cin, L.cout, cin_phys, KCW, NTW, &nch, &ntiles, &ntlast);
+        CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+        a.wpack = g_w; a.n_chunks = nch; a.nt_last = ntlast;
+        a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gw::TH - 1) / Gw::TH;
+        a.out0 = OutDesc{g_out, L.out_stride, L.out_off, (L.cout + 3) & ~3};
+        a.out1 = a.out0;
+        auto kern = dcscn::conv_wino<NTW, KCW, WPSW>;
+        if (ABL == 7) { a.act = ACT_NONE; a.alpha = reinterpret_cast<const float*>(g_dbg); CK(hipMemset(g_dbg, 0, (size_t)(1024 + 4096 * 16 + 8 * 65536) * 8)); }
+        const size_t lds = (size_t)dcscn::WinoGeom<NTW, KCW>::BUF * sizeof(float) * (size_t)g_lds_mul;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int occ = 0;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WAVES, lds));
+        CK(hipMemset(g_out, 0, (size_t)N * H * W * L.out_stride * sizeof(float)));
+        const float ms = time_kernel(kern, dim3(N * a.tiles_y * a.tiles_x, ntiles), lds, a, 5, 64 * WAVES);
+        // compare on a sample of images
+        const size_t cnt = (size_t)8 * H * W * L.out_stride;
+        std::vector<float> r(cnt), o(cnt);
+        CK(hipMemcpy(r.data(), g_ref, cnt * sizeof(float), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(o.data(), g_out, cnt * sizeof(float), hipMemcpyDeviceToHost));
+        double maxd = 0, maxv = 0;
+        for (size_t px = 0; px < (size_t)8 * H * W; ++px)
+            for (int c = 0; c < L.cout; ++c) {
+                const size_t i = px * L.out_stride + L.out_off + c;
+                maxd = std::fmax(maxd, std::fabs((double)r[i] - o[i]));
+                maxv = std::fmax(maxv, std::fabs((double)r[i]));
+            }
+        if (ABL == 7) {
+            std::vector<long long> d(1024 + 4096 * 16 + 8 * 65536);
+            CK(hipMemcpy(d.data(), g_dbg, d.size() * 8, hipMemcpyDeviceToHost));
+            double sum[4] = {0, 0, 0, 0};
+            int cnt = 0;
+            for (int b = 0; b < 4096; ++b)
+                for (int w = 0; w < 4; ++w) {
+                    const long long* e = &d[1024 + ((size_t)b * 4 + w) * 4];
+                    if (e[2] == 0) continue;
+                    for (int i = 0; i < 4; ++i) sum[i] += (double)e[i];
+                    ++cnt;
+                }
+            double ct = 0, rt = 0;
+            for (int b = 0; b < 512; ++b) { ct += (double)d[2 * b]; rt += (double)d[2 * b + 1]; }
+            printf("   shader clock while this kernel runs: %.0f MHz (s_memtime ticks per s_memrealtime 100 MHz tick)\n", ct / rt * 100.0);
+            {
+                const long long* life = &d[1024 + 4096 * 16];
+                long long tmin = -1, tmax = 0;
+                double occ_ticks = 0, cyc = 0, pro = 0, loop = 0, epi = 0, drain = 0;
+                int nwg = 0;
+                for (int g = 0; g < 65536; ++g) {
+                    const long long* e = life + 8 * (size_t)g;
+                    if (e[1] == 0) continue;
+                    if (tmin < 0 || e[0] < tmin) tmin = e[0];
+                    if (e[1] > tmax) tmax = e[1];
+                    occ_ticks += (double)(e[1] - e[0]);
+                    cyc += (double)(e[3] - e[2]);
+                    pro += (double)(e[4] - e[2]); loop += (double)(e[5] - e[4]); epi += (double)(e[6] - e[5]); drain += (double)(e[3] - e[6]);
+                    ++nwg;
+                }
+                const double span = (double)(tmax - tmin);
+                printf("   %d workgroups: device span %.3f ms, mean lifetime %.1f us = %.0f cycles (%.0f MHz), slot occupancy %.1f%% of 512\n",
+                       nwg, span / 1e5, occ_ticks / nwg / 100.0, cyc / nwg, cyc / occ_ticks * 100.0, occ_ticks / (span * 512.0) * 100.0);
+                {
+                    printf("   chunk-loop cycles by dispatch-order decile:");
+                    const int tot = nwg;
+                    for (int dcl = 0; dcl < 10; ++dcl) {
+                        double sm = 0; int cn = 0;
+                        for (int g = dcl * tot / 10; g < (dcl + 1) * tot / 10; ++g) {
+                            const long long* e = life + 8 * (size_t)g;
+                            if (e[1] == 0) continue;
+                            sm += (double)(e[5] - e[4]); ++cn;
+                        }
+                        printf(" %.0f", cn ? sm / cn : 0.0);
+                    }
+                    printf("\n");
+                }
+                printf("   wave 0 cycles: prologue %.0f  chunk loop %.0f  output transform + store issue %.0f  store drain %.0f\n",
+                       pro / nwg, loop / nwg, epi / nwg, drain / nwg);
+            }
+            printf("   phases per chunk (cycles, avg over %d waves, %d chunks): store %.0f  barrier1 %.0f  load+compute %.0f  barrier2 %.0f  total %.0f\n",
+                   cnt, nch, sum[0] / cnt / nch, sum[1] / cnt / nch, sum[2] / cnt / nch, sum[3] / cnt / nch,
+                   (sum[0] + sum[1] + sum[2] + sum[3]) / cnt / nch);
+        }
+        printf("%-8s %4d->%-4d SHIP W%d DB%d DMA%d P%d PF%d VP%d ABL%d NT%d KC%d WPS%d tiles%d lds %5.1f KB occ %d  %8.3f ms  %7.2f TFLOP/s(alg)  max|diff| %.3g (max|ref| %.3g)\n",
+               L.name, L.cin, L.cout, WAVES, (int)DBW, (int)DMA, PRIO, PF, (int)VPIPE, ABL, NTW, KCW, WPSW, ntiles, lds / 1024.0, occ, ms, flop / (ms * 1e-3) / 1e12, maxd, maxv);
+    }
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     if (argc > 1) N = atoi(argv[1]);
     if (getenv("WINO_LDS_MUL")) g_lds_mul = atoi(getenv("WINO_LDS_MUL"));
@@ -357,11 +479,10 @@ int main(int argc, char** argv) {
     const Layer cnn8{"CNN8", 97, 86, 1316, 984, 1316, 1084};
     const Layer cnn12{"CNN12", 57, 48, 1316, 1248, 1316, 1268};
     const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
-    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);      // shipped
-    run<2, 11, 3, 4, 2, false, 9, 4, false, 0, 3>(cnn2);      // input-tile loads coalesced (wrong data)
-    run<2, 11, 3, 4, 2, false, 11, 4, false, 0, 3>(cnn2);     // + filters L1-hot
-    run<2, 11, 3, 4, 2, true, 9, 4, false, 0, 3>(cnn2);       // pipelined staging, coalesced
-    run<2, 11, 3, 4, 2, true, 11, 4, false, 0, 3>(cnn2);
-    run<2, 11, 3, 4, 2, false, 1, 4, false, 0, 3>(cnn2);      // no loads in the loop
+    run_shipped<2, 11, 3, 4, 2>(cnn2);                          // csrc/conv_wino.hpp as built into the library
+    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);        // the same configuration of the lab kernel
+    run_fs<2, 11, 3, 2>(cnn2);
+    run_shipped<2, 8, 3, 4, 2>(cnn5);
+    run_shipped<4, 1, 1, 8, 4>(Layer{"tail16", 166, 16, 1316, 196, 1316, 364});
     return 0;
 }
