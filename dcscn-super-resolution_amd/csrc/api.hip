@@ -742,7 +742,11 @@ int finalize_op(dcscn_ctx* h, Op& op) {
         const int cin = (int)op.chan_map.size();
         std::vector<float> w((size_t)taps * op.cin_phys, 0.0f);
         for (int t = 0; t < taps; ++t)
-            for (int ci = 0; ci < cin; ++ci) w[(size_t)t * op.cin_phys + op.chan_map[ci]] = tw.data[(size_t)t * cin + ci];
+            for (int ci = 0; ci < cin; ++ci) {
+                float v = tw.data[(size_t)t * cin + ci];
+                if (s.dw1 >= 0) v = h->tensors[s.dw1].data[ci] * v;          // folded 1x1 depthwise half (ColSeg::dw1)
+                w[(size_t)t * op.cin_phys + op.chan_map[ci]] = v;
+            }
         return upload(h, w.data(), w.size() * sizeof(float), (void**)&op.d_w);
     }
     if (op.kind == OP_CIN1) {
