@@ -64,3 +64,23 @@ def test_random_flag_surface(oracle, seed):
                 assert float(np.max(np.abs(yt - ref))) <= 1e-4, (flags, n, h, w, opts)
     err = float(np.max(np.abs(y - ref)))
     assert np.isfinite(y).all() and err <= 1e-4, (err, flags, n, h, w, opts)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_self_ensemble(oracle, seed):
+    """Device-side flip gather + inverse-flip float64 mean (ensemble.hip) against the oracle's do() for random
+    non-square shapes, scales and ensemble sizes; each flip type must also be exact on its own."""
+    from dcscn_amd import engine
+    rng = np.random.default_rng(2000 + seed)
+    scale = int(rng.choice([2, 3, 4]))
+    cfg = oracle.make_config(layers=2, filters=12, min_filters=8, scale=scale, nin_filters=6, nin_filters2=5)
+    weights = oracle.synthetic_weights(cfg, seed=seed)
+    h, w = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+    n_ens = int(rng.integers(1, 9))
+    x, x2 = synthetic_batch(1, h, w, scale, seed=seed + 3)
+    ref = oracle.do(cfg, weights, x[0], x2[0], self_ensemble=n_ens, dtype=np.float64)
+    with engine.Engine(cfg, device=0) as eng:
+        eng.load_weights(weights)
+        y = eng.forward_ensemble(x[0], x2[0], n_ens)
+    assert y.dtype == np.float64 and y.shape == ref.shape
+    assert float(np.max(np.abs(y - ref))) <= 1e-4, (h, w, scale, n_ens)
