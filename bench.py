@@ -37,6 +37,33 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dens
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_north_star(dom_ms, nin_ms):
+    """The two figures BASELINE.json's north_star names, from the committed PMC passes + this run's kernel times:
+    HBM GB/s on the 3x3 feature stack (vs 8 TB/s) and matrix-pipe utilisation of the 1x1 NIN GEMM."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_dispatch.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            kernels = json.load(f)["kernels"]
+        out = {"source": os.path.basename(files[-1])}
+        tr = pmc_traffic(0)
+        if tr and dom_ms > 0:
+            gbs = tr["bytes_per_step"] / (dom_ms * 1e-3) / 1e9
+            out["hbm_3x3_stack"] = {"achieved_GBps": round(gbs, 1), "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                    "note": "the 3x3 stack is a dense f32 contraction (AI 117-404 FLOP/B): MFMA bound, not HBM bound"}
+        for name, k in kernels.items():
+            if name.startswith("conv_igemm<1,") and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
+                active = k["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
+                out["nin_1x1"] = {"mfma_util": round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * active), 4),
+                                  "ms_per_step": round(nin_ms, 4),
+                                  "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x active cycles), fused B1+A1 GEMM"}
+        return out
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
 def pmc_traffic(n_launches):
     """HBM bytes per step of the dominant kernel from the committed rocprofv3 PMC passes of this same
     command (profiles/*_pmc_per_dispatch.json: FETCH_SIZE + WRITE_SIZE, KiB, summed over the 3x3
@@ -217,6 +244,9 @@ def main():
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_kernel.items())},
             "whole_net_tflops": round(2.0 * total_macs * lr_pixels / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms else None,
         }
+        if n == PATCHES_PER_GPU and not args.fold_tail:
+            nin_ms = sum(ms for o, ms in zip(ops, per_op_ms) if o["kernel"] == "conv_igemm" and o["kernel_size"] == 1)
+            result["north_star"] = pmc_north_star(dom_ms, nin_ms)
         if world == 1 and not args.no_cpu_baseline:
             import cpu_path_torch as T
             cs = min(args.cpu_sample, n)
