@@ -319,8 +319,15 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
             for (int ks = 0; ks < G::KQ; ++ks, As += 4 * G::PS, Bs += 4 * G::NS) {
                 float d[4][4], v[16];
                 if constexpr (ABLATE == 5) {
-                    // tuner only: no raw read / transform (operands forged from a register)
-                    static_for<0, 16>([&](auto f_) DCSCN_INL { v[decltype(f_)::value] = areg[0].x + (float)decltype(f_)::value; });
+                    // tuner only: no raw read / transform.  Operands forged from the lane id, made opaque once per
+                    // chunk (forging them from a staging register would put a vmcnt wait into the compute phase)
+                    float seed = (float)lane;
+                    asm volatile("" : "+v"(seed));
+                    static_for<0, 16>([&](auto f_) DCSCN_INL { v[decltype(f_)::value] = seed; });
+                } else if constexpr (ABLATE == 12) {
+                    // tuner only: raw patch read kept, transform replaced by copies (no VALU adds)
+                    read_raw(As, d);
+                    static_for<0, 16>([&](auto f_) DCSCN_INL { v[decltype(f_)::value] = d[decltype(f_)::value / 4][decltype(f_)::value % 4]; });
                 } else {
                     read_raw(As, d);
                     transform(d, v);

@@ -479,10 +479,9 @@ int main(int argc, char** argv) {
     const Layer cnn8{"CNN8", 97, 86, 1316, 984, 1316, 1084};
     const Layer cnn12{"CNN12", 57, 48, 1316, 1248, 1316, 1268};
     const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
-    run_shipped<2, 11, 3, 4, 2>(cnn2);                          // csrc/conv_wino.hpp as built into the library
-    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);        // the same configuration of the lab kernel
-    run_fs<2, 11, 3, 2>(cnn2);
-    run_shipped<2, 8, 3, 4, 2>(cnn5);
-    run_shipped<4, 1, 1, 8, 4>(Layer{"tail16", 166, 16, 1316, 196, 1316, 364});
+    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);
+    run<2, 11, 3, 4, 2, false, 5, 4, false, 0, 3>(cnn2);        // no raw read, no transform
+    run<2, 11, 3, 4, 2, false, 12, 4, false, 0, 3>(cnn2);       // raw read, no transform adds
+    run<2, 11, 3, 4, 2, false, 3, 4, false, 0, 3>(cnn2);        // no staging (barriers + compute)
     return 0;
 }
