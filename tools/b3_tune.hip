@@ -235,6 +235,158 @@ __global__ __launch_bounds__(256, 2) void conv_b3(const B3Args a) {
     });
 }
 
+// ---- second form: v_mfma_f32_32x32x16_bf16, 2 x 2 register tiles (64 pixels x 64 output channels per wave) ----
+// The 16x16x32 form above needs 427 B of LDS operand reads per 16-cycle MFMA; a 32x32x16 MFMA does twice the MACs
+// per operand byte, and a 2x2 tile block brings it to 512 B per 32-cycle MFMA (64 B/clk per CU).  Workgroup = 4 waves
+// = 16 x 16 output pixels x 64 output channels; wave w owns tile rows 4w .. 4w+3.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kTH2 = 16, kHP2 = (kTH2 + 2) * kHTW;          // 324 halo pixels
+constexpr int kXBytes2 = kHP2 * kPixB;                      // 67392
+constexpr int kWTap2 = 3 * 2 * 32 * kRowB;                  // 15360: [piece][32-channel tile][32 couts][80 B]
+
+__global__ __launch_bounds__(256, 1) void conv_b3w(const B3Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* Xs = lds;
+    unsigned char* Ws = lds + kXBytes2;
+    constexpr int W_VEC = kWTap2 / 16, W_LOADS = (W_VEC + 255) / 256;
+    constexpr int X_VEC = kHP2 * 12, X_LOADS = (X_VEC + 255) / 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kgl = lane >> 5;
+    const int pr = li >> 4, pc = li & 15;        // pixel of this lane inside a 2 x 16 M-tile
+
+    int bid = blockIdx.x;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int group = blockIdx.y;
+    const int y0 = ty * kTH2, x0 = tx * kTW;
+    const int H = a.H, W = a.W;
+
+    const uint16_t* w_base = a.w3 + (size_t)group * a.cb * 9 * (kWTap2 / 2);
+    f32x16 acc[2][2];
+    static_for<0, 2>([&](auto m_) DCSCN_INL {
+        static_for<0, 2>([&](auto n_) DCSCN_INL {
+            static_for<0, 16>([&](auto r_) DCSCN_INL { acc[decltype(m_)::value][decltype(n_)::value][decltype(r_)::value] = 0.0f; });
+        });
+    });
+    u32x4 wreg[W_LOADS];
+    auto load_w = [&](int blk, int tap) DCSCN_INL {
+        const uint16_t* src = w_base + ((size_t)blk * 9 + tap) * (kWTap2 / 2);
+        static_for<0, W_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            if (tid + 256 * i < W_VEC) wreg[i] = *reinterpret_cast<const u32x4*>(src + (size_t)(tid + 256 * i) * 8);
+        });
+    };
+    auto store_w = [&](int buf) DCSCN_INL {
+        static_for<0, W_LOADS>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            if (tid + 256 * i < W_VEC) *reinterpret_cast<u32x4*>(Ws + buf * kWTap2 + (tid + 256 * i) * 16) = wreg[i];
+        });
+    };
+
+    for (int blk = 0; blk < a.cb; ++blk) {
+        load_w(blk, 0);
+        __syncthreads();
+        // halo tile: 324 pixels x 192 B, zero outside the image (loaded in two halves to bound the staging registers)
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            u32x4 xreg[(X_LOADS + 1) / 2];
+            static_for<0, (X_LOADS + 1) / 2>([&](auto i_) DCSCN_INL {
+                constexpr int i = decltype(i_)::value;
+                const int item = tid + 256 * (i + half * ((X_LOADS + 1) / 2));
+                xreg[i] = u32x4{0, 0, 0, 0};
+                if (item < X_VEC) {
+                    const int hp = item / 12, pcs = item - hp * 12;
+                    const int hy = hp / kHTW, hx = hp - hy * kHTW;
+                    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+                    if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                        xreg[i] = *reinterpret_cast<const u32x4*>(a.x3 + ((((size_t)img * H + gy) * W + gx) * a.cb + blk) * 96 + pcs * 8);
+                }
+            });
+            static_for<0, (X_LOADS + 1) / 2>([&](auto i_) DCSCN_INL {
+                constexpr int i = decltype(i_)::value;
+                const int item = tid + 256 * (i + half * ((X_LOADS + 1) / 2));
+                if (item < X_VEC) {
+                    const int hp = item / 12, pcs = item - hp * 12;
+                    *reinterpret_cast<u32x4*>(Xs + hp * kPixB + pcs * 16) = xreg[i];
+                }
+            });
+        }
+        store_w(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) load_w(blk, tap + 1);
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            const unsigned char* wb = Ws + (tap & 1) * kWTap2 + li * kRowB + kgl * 16;
+            static_for<0, 2>([&](auto h_) DCSCN_INL {                       // two 16-channel halves of the block
+                constexpr int h = decltype(h_)::value;
+                bf16x8 xo[2][3], wo[2][3];
+                static_for<0, 2>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    const unsigned char* xp = Xs + ((4 * wave + 2 * m + pr + dy) * kHTW + pc + dx) * kPixB + h * 32 + kgl * 16;
+                    static_for<0, 3>([&](auto p_) DCSCN_INL { xo[m][decltype(p_)::value] = *reinterpret_cast<const bf16x8*>(xp + decltype(p_)::value * 64); });
+                });
+                static_for<0, 2>([&](auto n_) DCSCN_INL {
+                    constexpr int n = decltype(n_)::value;
+                    static_for<0, 3>([&](auto p_) DCSCN_INL {
+                        constexpr int p = decltype(p_)::value;
+                        wo[n][p] = *reinterpret_cast<const bf16x8*>(wb + (p * 2 + n) * 32 * kRowB + h * 32);
+                    });
+                });
+                static_for<0, 2>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    static_for<0, 2>([&](auto n_) DCSCN_INL {
+                        constexpr int n = decltype(n_)::value;
+                        f32x16 c = acc[m][n];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[n][2], xo[m][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[n][0], xo[m][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[n][1], xo[m][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[n][1], xo[m][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[n][0], xo[m][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo[n][0], xo[m][0], c, 0, 0, 0);
+                        acc[m][n] = c;
+                    });
+                });
+            });
+            if (tap + 1 < 9) store_w((tap + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D layout of 32x32: column = lane & 31 (pixel), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+    const int gx = x0 + pc;
+    if (gx >= W) return;
+    static_for<0, 2>([&](auto m_) DCSCN_INL {
+        constexpr int m = decltype(m_)::value;
+        const int gy = y0 + 4 * wave + 2 * m + pr;
+        if (gy < H) {
+            float* o = a.out + (((size_t)img * H + gy) * W + gx) * a.out_stride + a.out_off;
+            static_for<0, 2>([&](auto n_) DCSCN_INL {
+                constexpr int n = decltype(n_)::value;
+                static_for<0, 4>([&](auto q_) DCSCN_INL {
+                    constexpr int q = decltype(q_)::value;
+                    const int c = group * 64 + n * 32 + 8 * q + 4 * kgl;
+                    if (c < a.cout) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c);
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(a.alpha + c);
+                        f32x4 v = {acc[m][n][4 * q] + bv.x, acc[m][n][4 * q + 1] + bv.y, acc[m][n][4 * q + 2] + bv.z, acc[m][n][4 * q + 3] + bv.w};
+                        v.x = v.x > 0 ? v.x : av.x * v.x;
+                        v.y = v.y > 0 ? v.y : av.y * v.y;
+                        v.z = v.z > 0 ? v.z : av.z * v.z;
+                        v.w = v.w > 0 ? v.w : av.w * v.w;
+                        *reinterpret_cast<f32x4*>(o + c) = v;
+                    }
+                });
+            });
+        }
+    });
+}
+
 struct Layer { const char* name; int cin, cout, in_stride, in_off, out_stride, out_off; };
 
 static std::vector<float> rand_vec(size_t n, unsigned seed, float scale) {
@@ -364,6 +516,64 @@ void run(const Layer& L) {
     fflush(stdout);
 }
 
+void run_wide(const Layer& L) {
+    std::vector<float> w = rand_vec((size_t)9 * L.cin * L.cout, 777, 0.2f);
+    const double flop = 2.0 * 9 * L.cin * (double)L.cout * N * H * W;
+    const int cb = (L.cin + 31) / 32;
+    const int groups = (L.cout + 63) / 64;
+    std::vector<uint16_t> w3((size_t)groups * cb * 9 * (kWTap2 / 2), 0);
+    for (int t = 0; t < 9; ++t)
+        for (int c = 0; c < L.cin; ++c)
+            for (int o = 0; o < L.cout; ++o) {
+                uint16_t p[3];
+                split3(w[((size_t)t * L.cin + c) * L.cout + o], p);
+                const int g = o / 64, n = (o % 64) / 32, r = o % 32;
+                for (int q = 0; q < 3; ++q)
+                    w3[(((size_t)g * cb + c / 32) * 9 + t) * (kWTap2 / 2) + ((size_t)(q * 2 + n) * 32 + r) * (kRowB / 2) + c % 32] = p[q];
+            }
+    CK(hipMemcpy(g_w3, w3.data(), w3.size() * 2, hipMemcpyHostToDevice));
+    B3Args a{};
+    a.x3 = g_x3; a.w3 = g_w3; a.bias = g_bias; a.alpha = g_bias; a.out = g_out;
+    a.N = N; a.H = H; a.W = W; a.cb = cb; a.out_stride = L.out_stride; a.out_off = L.out_off; a.cout = (L.cout + 3) & ~3;
+    a.tiles_x = (W + kTW - 1) / kTW; a.tiles_y = (H + kTH2 - 1) / kTH2;
+    auto kern = conv_b3w;
+    const size_t lds = kXBytes2 + 2 * kWTap2;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, lds));
+    CK(hipMemset(g_out, 0, (size_t)N * H * W * L.out_stride * sizeof(float)));
+    const dim3 grid(N * a.tiles_y * a.tiles_x, groups);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a);
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int i = 0; i < 5; ++i) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, 0, a);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    CK(hipGetLastError());
+    const size_t cnt = (size_t)8 * H * W * L.out_stride;
+    std::vector<float> r(cnt), o(cnt);
+    CK(hipMemcpy(r.data(), g_ref, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(o.data(), g_out, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    double maxd = 0, maxv = 0;
+    for (size_t px = 0; px < (size_t)8 * H * W; ++px)
+        for (int c = 0; c < L.cout; ++c) {
+            const size_t i = px * L.out_stride + L.out_off + c;
+            maxd = std::fmax(maxd, std::fabs((double)r[i] - o[i]));
+            maxv = std::fmax(maxv, std::fabs((double)r[i]));
+        }
+    printf("%-8s %4d->%-4d bf16x3 32x32x16 2x2 tiles, groups%d cb%d lds %5.1f KB occ %d  %8.3f ms  %7.2f TFLOP/s (f32-equivalent)  max|diff vs f32| %.3g (max|ref| %.3g)\n",
+           L.name, L.cin, L.cout, groups, cb, lds / 1024.0, occ, best, flop / (best * 1e-3) / 1e12, maxd, maxv);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     if (argc > 1) N = atoi(argv[1]);
     const size_t act = (size_t)N * H * W * 1316;
@@ -386,7 +596,8 @@ int main(int argc, char** argv) {
     const Layer cnn2{"CNN2", 196, 166, 1316, 0, 1316, 196};
     const Layer cnn5{"CNN5", 133, 120, 1316, 512, 1316, 648};
     run<11, 3>(cnn2);
-    run<11, 6>(cnn2);
+    run_wide(cnn2);
     run<8, 4>(cnn5);
+    run_wide(cnn5);
     return 0;
 }
