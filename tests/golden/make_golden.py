@@ -82,5 +82,30 @@ def main():
         json.dump(goldens, f, indent=1)
 
 
+def set14():
+    """Adds the reference's data/set14 images and the float64-oracle PSNR of the shipped c-DCSCN x2 / x3 / x4
+    checkpoints on them (README.md:60-62: 32.74 / 29.47 / 27.76 dB) to goldens.json, keeping everything else."""
+    os.makedirs(os.path.join(HERE, "set14"), exist_ok=True)
+    files = sorted(os.listdir(os.path.join(REF, "data", "set14")))
+    for f in files:
+        shutil.copy(os.path.join(REF, "data", "set14", f), os.path.join(HERE, "set14", f))
+    images = [np.atleast_3d(np.array(Image.open(os.path.join(HERE, "set14", f)))) for f in files]
+    with open(os.path.join(HERE, "goldens.json")) as f:
+        goldens = json.load(f)
+    entry = {"files": files}
+    for key in ("L7_x2", "L7_x3", "L7_x4"):
+        cfg = O.make_config(**MODELS[key][0])
+        weights = dict(np.load(os.path.join(HERE, "weights_%s.npz" % key)))
+        psnrs = [O.evaluate_image(cfg, weights, img)[0] for img in images]
+        entry[key] = {"psnr": psnrs, "mean": float(np.mean(psnrs))}
+        print("set14", key, entry[key]["mean"], flush=True)
+    goldens["set14"] = entry
+    with open(os.path.join(HERE, "goldens.json"), "w") as f:
+        json.dump(goldens, f, indent=1)
+
+
 if __name__ == "__main__":
-    main()
+    if "--set14" in sys.argv:
+        set14()
+    else:
+        main()

@@ -42,6 +42,19 @@ def test_set5_psnr_matches_oracle(tmp_path, key):
     assert abs(float(np.mean(psnrs)) - g["models"][key]["set5_mean"]) <= 1e-3
 
 
+@pytest.mark.parametrize("key", ["L7_x2", "L7_x3", "L7_x4"])
+def test_set14_psnr_matches_oracle(tmp_path, key):
+    """Set14 (README.md:60-62: 32.74 / 29.47 / 27.76 dB for these checkpoints), including the grayscale image that
+    takes the monochrome branch of do_for_evaluate (DCSCN.py:688-696: uint8 'L'-mode resizes)."""
+    g, m = _model(tmp_path, key)
+    psnrs = [m.do_for_evaluate(os.path.join(GOLDEN, "set14", f))[0] for f in g["set14"]["files"]]
+    m.close()
+    want = g["set14"][key]["psnr"]
+    print(key, np.mean(psnrs), g["set14"][key]["mean"])
+    assert max(abs(a - b) for a, b in zip(psnrs, want)) <= 1e-3
+    assert abs(float(np.mean(psnrs)) - g["set14"][key]["mean"]) <= 1e-3
+
+
 def test_set5_psnr_self_ensemble_8(tmp_path):
     g, m = _model(tmp_path, "L7_x2", self_ensemble=8)
     psnrs = [m.do_for_evaluate(os.path.join(GOLDEN, "set5", f))[0] for f in g["files"]]
