@@ -104,8 +104,30 @@ def set14():
         json.dump(goldens, f, indent=1)
 
 
+def bsd100():
+    """Oracle PSNR on the reference's data/bsd100 (README.md:63-65: 31.61 / 28.52 / 27.06 dB).  The 100 images are NOT
+    copied (too large for a fixture); only the per-image numbers are recorded, as one more pin of the oracle."""
+    d = os.path.join(REF, "data", "bsd100")
+    files = sorted(os.listdir(d))
+    images = [np.atleast_3d(np.array(Image.open(os.path.join(d, f)))) for f in files]
+    with open(os.path.join(HERE, "goldens.json")) as f:
+        goldens = json.load(f)
+    entry = {"files": files, "note": "images not committed; numbers produced in the build container by make_golden.py --bsd100"}
+    for key in ("L7_x2", "L7_x3", "L7_x4"):
+        cfg = O.make_config(**MODELS[key][0])
+        weights = dict(np.load(os.path.join(HERE, "weights_%s.npz" % key)))
+        psnrs = [O.evaluate_image(cfg, weights, img)[0] for img in images]
+        entry[key] = {"psnr": psnrs, "mean": float(np.mean(psnrs))}
+        print("bsd100", key, entry[key]["mean"], flush=True)
+    goldens["bsd100"] = entry
+    with open(os.path.join(HERE, "goldens.json"), "w") as f:
+        json.dump(goldens, f, indent=1)
+
+
 if __name__ == "__main__":
-    if "--set14" in sys.argv:
+    if "--bsd100" in sys.argv:
+        bsd100()
+    elif "--set14" in sys.argv:
         set14()
     else:
         main()
