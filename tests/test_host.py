@@ -269,3 +269,23 @@ def test_resample_tables_reproduce_pillow():
         ref = np.asarray(Image.fromarray(img).resize([ow, oh], resample=Image.BICUBIC))
         got = one_axis(one_axis(img, ow).T.copy(), oh).T          # horizontal pass first, as Pillow
         assert np.array_equal(got, ref)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r01_bench_n1.json is the line `python bench.py` printed on the MI355X box: the keys the driver and the
+    judge read must all be there, with the metric / workload BASELINE.json names."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r01_bench_n1.json")) as f:
+        d = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].startswith("LR Mpixels/sec at 48x48 patches, L12_F196to48 x2")
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - 1024 * 48 * 48 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
