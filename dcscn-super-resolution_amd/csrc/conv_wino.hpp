@@ -55,7 +55,7 @@ struct WinoGeom {
 // free.  PF: how many frequencies ahead of their MFMAs the filter operands are read (hipcc on its own keeps a
 // single operand pair in flight and waits lgkmcnt(0) in front of every frequency).
 template <int NT, int NTV, int KC, int PF>
-__device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
+__device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem, int tile_id, int ntile) {
     using G = WinoGeom<NT, KC>;
     constexpr int THREADS = G::THREADS;
     static_assert(PF >= 1 && PF < 16, "filter operands are read 1..15 frequencies ahead");
@@ -66,12 +66,11 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
     const int lj = lane & 15;
     const int lk = lane >> 4;
 
-    int bid = blockIdx.x;
+    int bid = tile_id;
     const int tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
-    const int ntile = blockIdx.y;
     const int y0 = ty * G::TH;
     const int x0 = tx * G::TW;
     const int H = a.H, W = a.W;
@@ -320,12 +319,29 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
 template <int NT, int KC, int WPS, int PF = 3>
 __global__ __launch_bounds__(256, WPS) void conv_wino(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nt_valid = (blockIdx.y == gridDim.y - 1) ? a.nt_last : NT;   // block uniform
-    if (nt_valid == NT) conv_wino_body<NT, NT, KC, PF>(a, smem);
+    // XCD-aware decode of the 1-D grid.  Workgroup ids go round-robin over the 8 XCDs (own L2 each); the channel
+    // groups of one pixel tile all read the same input tile, so they get ids that are congruent mod 8 and close
+    // together: [8 tiles of group 0][the same 8 tiles of group 1] ... -- they land on ONE XCD at about the same time
+    // and all but the first find the input tile in that L2.
+    // With many groups the span is limited to `group_span` of them at a time (phases over the whole image set).
+    const int G = a.n_groups, S = a.group_span;
+    const int tiles8 = (a.N * a.tiles_y * a.tiles_x + 7) >> 3;            // blocks of 8 pixel tiles
+    int id = blockIdx.x;
+    const int phase_ids = tiles8 * 8 * S;
+    const int phase = id / phase_ids;
+    id -= phase * phase_ids;
+    const int gs = (G - phase * S) < S ? (G - phase * S) : S;               // groups in this phase (the last may be short)
+    const int q = id / (8 * gs), r = id - q * 8 * gs;
+    if (q >= tiles8) return;                                                // padding ids of a short last phase
+    const int ntile = phase * S + (r >> 3);
+    const int tile_id = q * 8 + (r & 7);
+    if (tile_id >= a.N * a.tiles_y * a.tiles_x) return;
+    const int nt_valid = (ntile == G - 1) ? a.nt_last : NT;                // block uniform
+    if (nt_valid == NT) conv_wino_body<NT, NT, KC, PF>(a, smem, tile_id, ntile);
     else if constexpr (NT >= 2) {
-        if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC, PF>(a, smem);
+        if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC, PF>(a, smem, tile_id, ntile);
         else if constexpr (NT >= 3) {
-            if (nt_valid == NT - 2) conv_wino_body<NT, NT - 2, KC, PF>(a, smem);
+            if (nt_valid == NT - 2) conv_wino_body<NT, NT - 2, KC, PF>(a, smem, tile_id, ntile);
         }
     }
 }

@@ -44,6 +44,8 @@ struct ConvArgs {
     const float* dww;         // [dwk*dwk][cin_phys], physical channel order, zero padded (or nullptr)
     int32_t dwk;              // depthwise kernel size: 0 (none), 1 or 3
     int32_t nt_last;          // conv_wino: 16-channel tiles that are real in the last channel group
+    int32_t n_groups;         // conv_wino: channel groups of the launch (the kernel decodes (pixel tile, group) from a 1-D grid)
+    int32_t group_span;       // conv_wino: how many consecutive groups share the XCD-interleaved id range (divides the work in phases)
     // Folded linear tail (5x5 kernels): the launch computes, for every LR pixel, `ps*ps` sub-pixel phases
     // x 4 border variants of the composite [pixel-shuffler conv -> depth_to_space -> 3x3 conv to 1 channel];
     // conv channel v = phase * 4 + variant.  The epilogue picks the variant of each phase from the pixel's

@@ -382,7 +382,9 @@ void run_shipped(const Layer& L) {
         int occ = 0;
         CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * WAVES, lds));
         CK(hipMemset(g_out, 0, (size_t)N * H * W * L.out_stride * sizeof(float)));
-        const float ms = time_kernel(kern, dim3(N * a.tiles_y * a.tiles_x, ntiles), lds, a, 5, 64 * WAVES);
+        a.n_groups = ntiles; a.group_span = ntiles < 3 ? ntiles : 3;
+        const int tiles8 = (N * a.tiles_y * a.tiles_x + 7) / 8;
+        const float ms = time_kernel(kern, dim3(tiles8 * 8 * a.group_span * ((ntiles + a.group_span - 1) / a.group_span)), lds, a, 5, 64 * WAVES);
         // compare on a sample of images
         const size_t cnt = (size_t)8 * H * W * L.out_stride;
         std::vector<float> r(cnt), o(cnt);
@@ -479,9 +481,10 @@ int main(int argc, char** argv) {
     const Layer cnn8{"CNN8", 97, 86, 1316, 984, 1316, 1084};
     const Layer cnn12{"CNN12", 57, 48, 1316, 1248, 1316, 1268};
     const Layer upps{"Up-PS", 96, 384, 96, 0, 384, 0};
-    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);
-    run<2, 11, 3, 4, 2, false, 5, 4, false, 0, 3>(cnn2);        // no raw read, no transform
-    run<2, 11, 3, 4, 2, false, 12, 4, false, 0, 3>(cnn2);       // raw read, no transform adds
-    run<2, 11, 3, 4, 2, false, 3, 4, false, 0, 3>(cnn2);        // no staging (barriers + compute)
+    run_shipped<2, 11, 3, 4, 2>(cnn2);                          // csrc/conv_wino.hpp as built into the library
+    run<2, 11, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn2);        // the same loop in the lab kernel (2-D grid, no XCD-aware ids)
+    run_shipped<2, 8, 3, 4, 2>(cnn5);
+    run<2, 8, 3, 4, 2, false, 0, 4, false, 0, 3>(cnn5);
+    run_shipped<4, 1, 1, 8, 4>(Layer{"tail16", 166, 16, 1316, 196, 1316, 364});
     return 0;
 }
