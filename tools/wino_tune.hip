@@ -336,7 +336,7 @@ void run_fs(const Layer& L) {
 }
 
 // the SHIPPED kernel (csrc/conv_wino.hpp) against the direct kernel
-template <int MT, int NTD, int NTW, int KCS, int WPSW>
+template <int MT, int NTD, int NTW, int KCS, int WPSW, int PFS = 3>
 void run_shipped(const Layer& L) {
     constexpr int KCW = KCS, WAVES = 4, ABL = 0, PRIO = 0, PF = 0;
     constexpr bool DBW = false, DMA = false, VPIPE = false;
@@ -375,7 +375,7 @@ void run_shipped(const Layer& L) {
         a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gw::TH - 1) / Gw::TH;
         a.out0 = OutDesc{g_out, L.out_stride, L.out_off, (L.cout + 3) & ~3};
         a.out1 = a.out0;
-        auto kern = dcscn::conv_wino<NTW, KCW, WPSW>;
+        auto kern = dcscn::conv_wino<NTW, KCW, WPSW, PFS>;
         if (ABL == 7) { a.act = ACT_NONE; a.alpha = reinterpret_cast<const float*>(g_dbg); CK(hipMemset(g_dbg, 0, (size_t)(1024 + 4096 * 16 + 8 * 65536) * 8)); }
         const size_t lds = (size_t)dcscn::WinoGeom<NTW, KCW>::BUF * sizeof(float) * (size_t)g_lds_mul;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
