@@ -51,6 +51,7 @@ struct ConvArgs {
     // conv channel v = phase * 4 + variant.  The epilogue picks the variant of each phase from the pixel's
     // position and stores one value per HR pixel into out0 (stride 1), plus `res`.
     int32_t fold;
+    const float* zeros;       // conv_wino2: >= 16 bytes of zeros in device memory (LDS-DMA source for SAME padding / channel tails)
 };
 
 struct ConvShape {            // kernel variant picked by the plan
