@@ -78,7 +78,7 @@ def pmc_traffic(n_launches):
             kernels = json.load(f)["kernels"]
         total = 0.0
         for name, k in kernels.items():
-            if (name.startswith("conv_igemm<3,") or name.startswith("conv_wino<")) and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+            if (name.startswith("conv_igemm<3,") or name.startswith("conv_wino")) and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
                 per_forward = k["dispatches"] / max(k.get("forwards", 4), 1)
                 total += (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 * per_forward
         return {"bytes_per_step": total, "unit": "B", "source": os.path.basename(files[-1]),
@@ -181,7 +181,7 @@ def main():
         ops = eng.ops()
         lr_pixels = n * PATCH * PATCH
         # dominant kernel: the 3x3 implicit-GEMM conv launches (CNN2..12, B2, Up-PS)
-        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino")
+        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino", "conv_wino2")
                and o["kernel_size"] == 3 and o["out_channels"] > 1]
         dom_kernels = sorted({o["kernel"] for o, _ in dom})
         dom_flop = sum(2.0 * o["macs_per_lr_pixel"] for o, _ in dom) * lr_pixels
@@ -193,7 +193,7 @@ def main():
         kernel_ms = sum(per_op_ms)
         per_kernel = {}
         for o, ms in zip(ops, per_op_ms):
-            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] in ("conv_igemm", "conv_wino") else "")
+            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] in ("conv_igemm", "conv_wino", "conv_wino2") else "")
             per_kernel[key] = per_kernel.get(key, 0.0) + ms
         if args.ops:
             for o, ms in zip(ops, per_op_ms):

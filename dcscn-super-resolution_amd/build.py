@@ -15,11 +15,13 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_NAME = "libdcscn_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
-SOURCES = ["api.hip", "kernels.hip", "resample.hip", "ensemble.hip", "conv_k1.hip", "conv_k3.hip", "conv_k5.hip", "conv_k7.hip", "conv_wino.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "conv_igemm.hpp", "conv_wino.hpp", "conv_variants.hpp")] + \
+SOURCES = ["api.hip", "kernels.hip", "resample.hip", "ensemble.hip", "conv_k1.hip", "conv_k3.hip", "conv_k5.hip", "conv_k7.hip", "conv_wino2.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "conv_igemm.hpp", "conv_wino2.hpp", "conv_variants.hpp")] + \
           [os.path.join(INCLUDE, "dcscn.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-source extra flags (see the comment at the top of conv_wino2.hip)
+EXTRA_FLAGS = {"conv_wino2.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc_path():
@@ -55,7 +57,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src_path] + HEADERS):
-            jobs.append([hipcc] + FLAGS + ["-I", INCLUDE, "-c", src_path, "-o", obj])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-I", INCLUDE, "-c", src_path, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
             for out in pool.map(_run, jobs):

@@ -88,7 +88,6 @@ struct Op {
     float out_scale = 1.0f;         // OP_COUT1: pointwise scalar of a separable 1->1 conv
     int tconv_s = 0;                // > 0: the op is tf.nn.conv2d_transpose with this stride, run as its
                                     // equivalent 3x3 conv to s*s*C channels + depth_to_space (see add_tconv)
-    bool wino_tail = false;         // the 1-tile tail group of a layer, split off by split_wino_tails()
     int fold_s = 0;                 // > 0: folded linear tail (see fold_linear_tail): pixel-shuffler block
     int fold_c = 0;                 //      channels after depth_to_space
     int fold_rw = -1;               //      filter tensor of the last reconstruction conv [3, 3, C, 1]
@@ -101,7 +100,7 @@ struct Op {
     // conv_igemm variant
     ConvShape shape{3, 2, 1, 4};
     int n_tiles = 1, n_chunks = 0, ctot = 0;
-    int nt_last = 0;                // Winograd: channel tiles in the last group
+    int n_full = 0;                 // Winograd: groups [0, n_full) hold shape.nt channel tiles, the others shape.nt - 1
     // accounting
     int64_t macs = 0, bytes = 0;
     // device copies
@@ -612,50 +611,15 @@ int op_tiles16(const Op& op) {
     return (ctot + 15) / 16;
 }
 
-// Winograd F(2x2,3x3) for 3x3 convs with enough input channels to amortise the transforms (measured on MI355X:
-// 1.25-1.35x over conv_igemm from 57 input channels up; the tiny layers of the c-DCSCN models stay on the direct
-// kernel).  The Winograd kernel's cost follows its number of channel groups (ceil(tiles / 3)), not its MFMA count;
-// a 3k+1-tile layer gets its last tile from split_wino_tails (before that existed, 4 tiles = 3 + 1 were faster on
-// the direct kernel: CNN11 66->57 1.37 vs 1.49 ms).  (op.vec4: the Winograd epilogue only has the 16-byte store form.)
+// Winograd F(2x2,3x3) (conv_wino2) for 3x3 convs with enough input channels to amortise the transforms (measured on
+// MI355X: 1.25-1.35x over conv_igemm from 57 input channels up; the tiny layers of the c-DCSCN models stay on the direct
+// kernel).  A layer's 16-channel tiles are spread evenly over ceil(tiles / 3) channel groups (10 tiles = 3+3+2+2): a
+// group's cost is only partly its MFMA count (the input tile and its transform are per group), so a 1-tile group costs
+// ~70 % of a 3-tile one.  (op.vec4: the Winograd epilogue only has the 16-byte store form.)
 bool wino_eligible(const dcscn_ctx* h, const Op& op) {
     const int tiles16 = op_tiles16(op);
     return h->winograd && op.kind == OP_CONV && op.vec4 && op.ks == 3 && op.dwk == 0 && op.cin_phys >= 32 &&
            op.segs.size() == 1 && op.tconv_s == 0 && tiles16 >= 2;
-}
-
-// A layer whose 16-channel tiles do not fill groups of 3 ends in a 1-tile group that costs almost as much as a
-// full one in the 3-tile kernel (CNN3 148 = 3+3+3+1 tiles: 1.23 of 6.1 ms): its time is the input-tile loads, not
-// MFMAs.  Such a tail is split off into its own launch of the 1-tile kernel with 8-channel chunks at 4 waves per
-// SIMD (0.85 ms, tools/wino_tune.hip "tail16"); both launches read the same input and write adjacent channel slices.
-void split_wino_tails(dcscn_ctx* h) {
-    std::vector<Op> out;
-    for (const Op& op : h->ops) {
-        const int tiles16 = op_tiles16(op);
-        if (!wino_eligible(h, op) || tiles16 < 4 || tiles16 % 3 != 1 || op.ps != 1 || op.fold_s > 0 || op.segs[0].dst != 0) {
-            out.push_back(op);
-            continue;
-        }
-        const int head = 16 * (tiles16 - 1);              // channels of the full groups
-        Op a = op, b = op;
-        a.cout = head;
-        a.segs[0].cout = head;
-        a.out_width[0] = head;
-        b.name = op.name + " (tail)";
-        b.wino_tail = true;
-        b.cout = op.cout - head;
-        b.segs[0].cout = op.cout - head;
-        b.segs[0].col0 = op.segs[0].col0 + head;
-        b.out_off[0] = op.out_off[0] + head;
-        b.out_width[0] = op.out_width[0] - head;
-        a.macs = op.macs * head / op.cout;
-        b.macs = op.macs - a.macs;
-        const int64_t r2 = (int64_t)op.res * op.res;
-        b.bytes = 4 * r2 * b.out_width[0];               // the input is counted once, with the head
-        a.bytes = op.bytes - b.bytes;
-        out.push_back(a);
-        out.push_back(b);
-    }
-    h->ops.swap(out);
 }
 
 // ---- optional graph rewrite: the linear tail as one conv ----------------------------------------
@@ -829,46 +793,54 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     int ctot = 0;
     for (const ColSeg& s : op.segs) ctot = std::max(ctot, s.dst + s.cout);
     const int tiles16 = (ctot + 15) / 16;
-    if (wino_eligible(h, op) || op.wino_tail) {      // see wino_eligible / split_wino_tails
-        const int nt = std::min(kWinoMaxNT, tiles16);
-        op.shape = ConvShape{3, 4, nt, op.wino_tail ? kWinoTailKC : kWinoKC, 0, 1};
-        op.n_tiles = (tiles16 + nt - 1) / nt;
-        op.nt_last = tiles16 - (op.n_tiles - 1) * nt;
+    if (wino_eligible(h, op)) {
+        op.n_tiles = (tiles16 + kWinoMaxNT - 1) / kWinoMaxNT;                 // channel groups
+        const int nt = (tiles16 + op.n_tiles - 1) / op.n_tiles;               // tiles of the wide groups
+        op.n_full = tiles16 - op.n_tiles * (nt - 1);                          // how many groups are wide; the others hold nt - 1
+        op.shape = ConvShape{3, 4, nt, kWinoKC, 0, 1};
         op.ctot = op.n_tiles * nt * 16;
-        const int kc = op.shape.kc;
+        const int kc = kWinoKC;
         op.n_chunks = (op.cin_phys + kc - 1) / kc;
         const int ns = conv_ns(nt);
         const size_t chunk_floats = (size_t)16 * kc * ns;
-        // + one staging sweep of slack: the kernel loads the last partial sweep of a chunk with every
-        // thread (only the LDS store is predicated), which may run past the final chunk by < 2048 floats
-        std::vector<float> pack((size_t)op.n_tiles * op.n_chunks * chunk_floats + 2048, 0.0f);
+        std::vector<float> pack((size_t)op.n_tiles * op.n_chunks * chunk_floats, 0.0f);
         std::vector<float> bias(op.ctot, 0.0f), alpha(op.ctot, 0.0f);
         const ColSeg& sg = op.segs[0];
         const TensorSpec& tw = w_override ? *w_override : h->tensors[sg.w];   // [3, 3, cin, cout]
         const int cin = (int)op.chan_map.size();
         const int wcols = w_override ? sg.cout : (int)tw.shape.back();
+        // conv channel -> slot of the padded [group][nt * 16] layout (bias, slope and filter columns)
+        auto padded = [&](int cc) {
+            const int t = cc / 16;
+            const int wide = op.n_full * nt;                                   // tiles held by the wide groups
+            const int g = t < wide ? t / nt : op.n_full + (t - wide) / (nt - 1);
+            const int tg = t < wide ? t % nt : (t - wide) % (nt - 1);
+            return (g * nt + tg) * 16 + cc % 16;
+        };
         static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
         for (int ci = 0; ci < cin; ++ci) {
             const int kp = op.chan_map[ci];
-            const int chunk = kp / kc, kk = kp % kc;
+            const int chunk = kp / kc, c8 = kp % kc;
+            const int row = (c8 & 1) * 4 + (c8 >> 1);                          // k-step c8 & 1, MFMA k index c8 >> 1
             for (int co = 0; co < sg.cout; ++co) {
                 double g[3][3], gg[4][3];
                 for (int i = 0; i < 3; ++i)
                     for (int j = 0; j < 3; ++j) g[i][j] = tw.data[((size_t)(i * 3 + j) * cin + ci) * wcols + sg.col0 + co];
                 for (int xi = 0; xi < 4; ++xi)                      // G g
                     for (int j = 0; j < 3; ++j) gg[xi][j] = G[xi][0] * g[0][j] + G[xi][1] * g[1][j] + G[xi][2] * g[2][j];
-                const int cc = sg.dst + co;
-                const int tile = cc / (nt * 16), jn = cc % (nt * 16);
+                const int pc = padded(sg.dst + co);
+                const int grp = pc / (nt * 16), jn = pc % (nt * 16);
                 for (int xi = 0; xi < 4; ++xi)
                     for (int nu = 0; nu < 4; ++nu) {                // (G g) G^T, float64, rounded once
                         const double u = gg[xi][0] * G[nu][0] + gg[xi][1] * G[nu][1] + gg[xi][2] * G[nu][2];
-                        pack[((size_t)tile * op.n_chunks + chunk) * chunk_floats + ((size_t)(xi * 4 + nu) * kc + kk) * ns + jn] = (float)u;
+                        pack[((size_t)grp * op.n_chunks + chunk) * chunk_floats + ((size_t)(xi * 4 + nu) * kc + row) * ns + jn] = (float)u;
                     }
             }
         }
         for (int co = 0; co < sg.cout; ++co) {
-            if (sg.b >= 0) bias[sg.dst + co] = h->tensors[sg.b].data[sg.col0 + co];
-            alpha[sg.dst + co] = sg.alpha >= 0 ? h->tensors[sg.alpha].data[sg.col0 + co] : op.const_alpha;
+            const int pc = padded(sg.dst + co);
+            if (sg.b >= 0) bias[pc] = h->tensors[sg.b].data[sg.col0 + co];
+            alpha[pc] = sg.alpha >= 0 ? h->tensors[sg.alpha].data[sg.col0 + co] : op.const_alpha;
         }
         int rcw = upload(h, pack.data(), pack.size() * sizeof(float), (void**)&op.d_w);
         if (!rcw) rcw = upload(h, bias.data(), bias.size() * sizeof(float), (void**)&op.d_bias);
@@ -1019,7 +991,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     a.N = nb; a.H = Hr; a.W = Wr;
     a.tiles_x = (Wr + 15) / 16;
     a.tiles_y = (Hr + 4 * op.shape.mt - 1) / (4 * op.shape.mt);
-    a.nt_last = op.nt_last;
+    a.n_full = op.n_full;
     for (int i = 0; i < 2; ++i) {
         OutDesc& o = i == 0 ? a.out0 : a.out1;
         const int id = op.out_buf[i];
@@ -1037,7 +1009,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     a.dww = op.d_dww;
     a.dwk = op.dwk;
     a.fold = op.fold_s > 0 ? 1 : 0;
-    if (op.shape.wino) HIP_TRY(h, wino_launch(op.shape.nt, op.shape.kc, a, op.n_tiles, stream));
+    if (op.shape.wino) HIP_TRY(h, wino_launch(op.shape.nt, a, op.n_tiles, stream));
     else HIP_TRY(h, conv_launch(op.shape, a, op.n_tiles, stream));
     return DCSCN_OK;
 }
@@ -1375,7 +1347,6 @@ int dcscn_finalize(dcscn_handle h) {
         if (!t.set) return fail(h, DCSCN_ERR_MISSING_TENSOR, "variable '%s' was never set", t.name.c_str());
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->fold_tail) fold_linear_tail(h);      // silently keeps the layer-by-layer graph where it does not apply
-    split_wino_tails(h);
     for (Op& op : h->ops) {
         int rc = finalize_op(h, op);
         if (rc) return rc;
@@ -1402,7 +1373,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     const Op& op = h->ops[index];
     memset(out, 0, sizeof *out);
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
-    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (op.shape.wino ? "conv_wino" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : "depthwise");
+    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (op.shape.wino ? "conv_wino2" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
     out->out_channels = op.cout;
@@ -1417,7 +1388,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
         const int64_t r2 = (int64_t)op.res * op.res;
         const int64_t k_exec = (int64_t)op.n_chunks * op.shape.kc;             // padded input channels
         if (op.shape.wino) {
-            const int64_t tiles = (int64_t)(op.n_tiles - 1) * op.shape.nt + op.nt_last;
+            const int64_t tiles = (int64_t)op.n_tiles * (op.shape.nt - 1) + op.n_full;
             out->executed_macs_per_lr_pixel = r2 * 4 * k_exec * tiles * 16;    // 16 products per 2x2 outputs
         } else {
             out->executed_macs_per_lr_pixel = r2 * op.ks * op.ks * k_exec * (int64_t)op.n_tiles * op.shape.nt * 16;

@@ -8,8 +8,8 @@
 // * Both operands reach LDS by `global_load_lds_dwordx4` (1 KB per wave instruction, no staging VGPRs, no ds_write pass,
 //   no mask VALU).  The DMA destination is lane-linear, so the LDS image is chosen by each lane's SOURCE address:
 //     filters  [f][s][k][NS]  -- the host packs exactly this image, the copy is linear;
-//     input    4 planes [channel quad h][x parity] of [18 rows][9] 16-byte slots; a slot holds 4 consecutive channels of
-//              one halo pixel.  Lanes whose halo pixel lies outside the image are masked off (EXEC): their slots are
+//     input    2 planes [x parity] of [18 rows][9 pixels][2 channel quads] 16-byte slots: lanes 2p, 2p+1 of a DMA fetch the
+//              32 contiguous bytes of one halo pixel (the 8 channels of the chunk).  Lanes whose halo pixel lies outside the image are masked off (EXEC): their slots are
 //              cleared once at kernel start and never written again -- that IS the SAME zero padding.
 // * 8 input channels per chunk = two MFMA k-steps per barrier, ONE barrier per chunk.  Two filter stages (filters of
 //   chunk c+1 land while chunk c computes) and two input stages running one chunk further ahead: the raw patch of chunk
@@ -27,6 +27,10 @@
 #pragma once
 #include "conv_igemm.hpp"
 
+#ifndef DCSCN_GLDS_AUX
+#define DCSCN_GLDS_AUX ""          // cache-policy suffix of the LDS-DMA loads (tuner: " nt", " sc1")
+#endif
+
 namespace dcscn {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -37,9 +41,9 @@ struct Wino2Geom {
     static constexpr int KC = 8;
     static constexpr int TH = 16, TW = 16;
     static constexpr int HTH = TH + 2, HTW = TW + 2;
-    static constexpr int ROW_SLOTS = HTW / 2;                 // 9 slots per plane row (one x parity)
-    static constexpr int PL = HTH * ROW_SLOTS;                // 162 slots per plane
-    static constexpr int A_SLOTS = 4 * PL;                    // 648
+    static constexpr int ROW_SLOTS = HTW / 2;                 // 9 pixels per plane row (one x parity)
+    static constexpr int PL = HTH * ROW_SLOTS;                // 162 pixels per parity plane
+    static constexpr int A_SLOTS = 4 * PL;                    // 648 slots: 2 planes x 162 pixels x 2 channel quads
     static constexpr int A_DMA = (A_SLOTS + 63) / 64;         // 11 wave instructions
     static constexpr int A_BYTES = A_DMA * 1024;
     static constexpr int NS = conv_ns(NT);
@@ -58,13 +62,14 @@ struct Wino2Geom {
 // compiler-reserved and is restored inside the same statement.  Completion is tracked by vmcnt; hipcc does not see the load.
 __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" DCSCN_GLDS_AUX "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst)
                  : "memory");
 }
 
-template <int NT, int NTV, int PF>
+// ABL (tuner only, tools/wino2_tune.hip): 0 shipped; 1 no DMA in the K loop; 2 no vmcnt wait; 3 no filter DMA; 4 no input DMA; 5 no barrier (+ no wait)
+template <int NT, int NTV, int PF, int ABL = 0>
 __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, int tile_id, int ntile) {
     using G = Wino2Geom<NT>;
     static_assert(PF >= 1 && PF < 16, "filter operands are read 1..15 frequencies ahead");
@@ -95,16 +100,18 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
     static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
         const int slot = (wave + 4 * r) * 64 + lane;
-        const int plane = slot / G::PL;
-        const int rem = slot - plane * G::PL;
+        const int hq = slot & 1;                             // channel quad of the chunk: lanes 2p, 2p+1 fetch 32 contiguous bytes of one pixel
+        const int pix = slot >> 1;
+        const int par = pix / G::PL;
+        const int rem = pix - par * G::PL;
         const int row = rem / G::ROW_SLOTS;
         const int xs = rem - row * G::ROW_SLOTS;
-        const int hx = 2 * xs + (plane & 1);
+        const int hx = 2 * xs + par;
         const int gy = y0 - 1 + row;
         const int gx = x0 - 1 + hx;
         a_inb[r] = slot < G::A_SLOTS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        a_hi[r] = (plane >> 1) != 0;
-        a_off[r] = (unsigned)(((row * W + hx) * a.in_stride + 4 * (plane >> 1)) * 4);
+        a_hi[r] = hq != 0;
+        a_off[r] = (unsigned)(((row * W + hx) * a.in_stride + 4 * hq) * 4);
     });
     const float* a_base = in_img + ((ptrdiff_t)(y0 - 1) * W + (x0 - 1)) * a.in_stride;    // wave-uniform
     const float* b_base = a.wpack + (size_t)ntile * a.n_chunks * G::B_FLOATS;             // wave-uniform
@@ -143,7 +150,7 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
     const int tr = 2 * wave + (lj >> 3);
     const int tc = lj & 7;
     // byte offset of the lane's raw-patch origin inside an input stage: plane pair of channel quad lk>>1, halves by lk&1
-    const int a_lane = ((lk >> 1) * 2 * G::PL + (2 * tr) * G::ROW_SLOTS + tc) * 16 + (lk & 1) * 8;
+    const int a_lane = ((2 * tr) * G::ROW_SLOTS + tc) * 32 + lk * 8;
     const int b_lane = G::B_BASE + (lk * G::NS + lj) * 4;
 
     // V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], on component C (channel 2k + C) of the raw patch
@@ -170,7 +177,7 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
     typedef const volatile __attribute__((address_space(3))) f32x2* lds_f32x2_ptr;
     auto read_raw1 = [&](auto i_, auto j_, unsigned As, f32x2 (&rr)[4][4]) DCSCN_INL {
         constexpr int i = decltype(i_)::value, jj = decltype(j_)::value;
-        rr[i][jj] = *(lds_f32x2_ptr)(uintptr_t)(As + ((jj & 1) * G::PL + i * G::ROW_SLOTS + (jj >> 1)) * 16);
+        rr[i][jj] = *(lds_f32x2_ptr)(uintptr_t)(As + ((jj & 1) * G::PL + i * G::ROW_SLOTS + (jj >> 1)) * 32);
     };
     // the 16*NTV MFMAs of one k-step, filter operands read PF frequencies ahead; hook(f) runs after the MFMAs of f
     auto mfma_step = [&](const float* Bs, const float (&v)[16], auto&& hook) DCSCN_INL {
@@ -225,8 +232,11 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
         mfma_step(Bs, v, [&](auto f_) DCSCN_INL {
             constexpr int f = decltype(f_)::value;
             // one DMA piece behind each of the first B_ROUNDS + A_ROUNDS frequencies
-            if constexpr (f >= 1 && f <= G::B_ROUNDS) dma_b(std::integral_constant<int, f - 1>{}, cb, sb ^ 1);
-            else if constexpr (f > G::B_ROUNDS && f <= G::B_ROUNDS + G::A_ROUNDS) dma_a(std::integral_constant<int, f - 1 - G::B_ROUNDS>{}, ca, sb);
+            if constexpr (f >= 1 && f <= G::B_ROUNDS) {
+                if constexpr (ABL != 1 && ABL != 3) dma_b(std::integral_constant<int, f - 1>{}, cb, sb ^ 1);
+            } else if constexpr (f > G::B_ROUNDS && f <= G::B_ROUNDS + G::A_ROUNDS) {
+                if constexpr (ABL != 1 && ABL != 4) dma_a(std::integral_constant<int, f - 1 - G::B_ROUNDS>{}, ca, sb);
+            }
         });
         transform(std::integral_constant<int, 1>{}, rr, v);
         mfma_step(Bs + 4 * G::NS, v, [&](auto f_) DCSCN_INL {
@@ -237,14 +247,16 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
                 read_raw1(std::integral_constant<int, (2 * (f - 8) + 1) / 4>{}, std::integral_constant<int, (2 * (f - 8) + 1) % 4>{}, An, rr);
             }
         });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (ABL != 2 && ABL != 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (ABL != 5) __syncthreads();
     }
+    if constexpr (ABL == 2 || ABL == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- output transform (wave-local) + epilogue: identical to conv_wino ----
     const int gy0 = y0 + 2 * tr;
     const int gx0 = x0 + 2 * tc;
-    const int cbase = ntile * NT * 16 + 4 * lk;
+    const int cbase = ntile * NT * 16 + 4 * lk;                                  // bias / slope index: padded group layout
+    const int obase = cbase - 16 * (ntile > a.n_full ? ntile - a.n_full : 0);    // conv channel: groups past n_full are one tile narrower
     const int act = a.act;
     const int ps = a.ps;
     const int orow = W * ps;                                   // destination pixels per row
@@ -262,7 +274,7 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
         const int act_e = ACT_C >= 0 ? ACT_C : act;
         static_for<0, NTV>([&](auto n_) DCSCN_INL {
             constexpr int n = decltype(n_)::value;
-            const int c = cbase + n * 16;
+            const int c = obase + n * 16;
             const bool first = c < a.split;
             float* optr = first ? a.out0.ptr : a.out1.ptr;
             const int ostride = first ? a.out0.stride : a.out1.stride;
@@ -318,7 +330,7 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
 }
 
 // launch_bounds' second argument is waves per SIMD = resident 4-wave workgroups per CU
-template <int NT, int WPS = 2, int PF = 3>
+template <int NT, int WPS = 2, int PF = 3, int ABL = 0>
 __global__ __launch_bounds__(256, WPS) void conv_wino2(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // XCD-aware decode of the 1-D grid (see conv_wino): the channel groups of one pixel tile get ids that are congruent
@@ -335,14 +347,8 @@ __global__ __launch_bounds__(256, WPS) void conv_wino2(const ConvArgs a) {
     const int ntile = phase * S + (r >> 3);
     const int tile_id = q * 8 + (r & 7);
     if (tile_id >= a.N * a.tiles_y * a.tiles_x) return;
-    const int nt_valid = (ntile == G - 1) ? a.nt_last : NT;                // block uniform
-    if (nt_valid == NT) conv_wino2_body<NT, NT, PF>(a, smem, tile_id, ntile);
-    else if constexpr (NT >= 2) {
-        if (nt_valid == NT - 1) conv_wino2_body<NT, NT - 1, PF>(a, smem, tile_id, ntile);
-        else if constexpr (NT >= 3) {
-            if (nt_valid == NT - 2) conv_wino2_body<NT, NT - 2, PF>(a, smem, tile_id, ntile);
-        }
-    }
+    if (ntile < a.n_full) conv_wino2_body<NT, NT, PF, ABL>(a, smem, tile_id, ntile);                 // block uniform
+    else if constexpr (NT >= 2) conv_wino2_body<NT, NT - 1, PF, ABL>(a, smem, tile_id, ntile);
 }
 
 }  // namespace dcscn

@@ -43,21 +43,20 @@ struct ConvArgs {
     // sum_t in(p + o_t)[c] * dww[t][c] instead of in(p)[c]
     const float* dww;         // [dwk*dwk][cin_phys], physical channel order, zero padded (or nullptr)
     int32_t dwk;              // depthwise kernel size: 0 (none), 1 or 3
-    int32_t nt_last;          // conv_wino: 16-channel tiles that are real in the last channel group
-    int32_t n_groups;         // conv_wino: channel groups of the launch (the kernel decodes (pixel tile, group) from a 1-D grid)
-    int32_t group_span;       // conv_wino: how many consecutive groups share the XCD-interleaved id range (divides the work in phases)
+    int32_t n_full;           // conv_wino2: channel groups [0, n_full) hold NT 16-channel tiles, the others NT - 1
+    int32_t n_groups;         // conv_wino2: channel groups of the launch (the kernel decodes (pixel tile, group) from a 1-D grid)
+    int32_t group_span;       // conv_wino2: how many consecutive groups share the XCD-interleaved id range (divides the work in phases)
     // Folded linear tail (5x5 kernels): the launch computes, for every LR pixel, `ps*ps` sub-pixel phases
     // x 4 border variants of the composite [pixel-shuffler conv -> depth_to_space -> 3x3 conv to 1 channel];
     // conv channel v = phase * 4 + variant.  The epilogue picks the variant of each phase from the pixel's
     // position and stores one value per HR pixel into out0 (stride 1), plus `res`.
     int32_t fold;
-    const float* zeros;       // conv_wino2: >= 16 bytes of zeros in device memory (LDS-DMA source for SAME padding / channel tails)
 };
 
 struct ConvShape {            // kernel variant picked by the plan
     int ks, mt, nt, kc;
     int dwk = 0;              // fused depthwise kernel size (ks == 1 only)
-    int wino = 0;             // 1: Winograd F(2x2,3x3) kernel (ks == 3, nt <= 3, 16x16 pixel tiles)
+    int wino = 0;             // 1: Winograd F(2x2,3x3) kernel conv_wino2 (ks == 3, nt <= 3, kc == 8, 16x16 pixel tiles)
 };
 
 // Geometry helpers shared by the weight packer (host) and the kernels (device).
@@ -74,13 +73,13 @@ size_t conv_lds_bytes(const ConvShape& s);
 // One-time: raise the dynamic-LDS limit of every instantiated kernel. Returns hipSuccess or error.
 hipError_t conv_init_kernels();
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream);
-// Winograd F(2x2,3x3) variant of a 3x3 conv: `nt` channel tiles of 16 per group (1..3), `n_groups` groups,
-// args.nt_last = tiles in the last group, args.wpack in the [group][chunk][16 f][kk][conv_ns(nt)] image.
-constexpr int kWinoKC = 4;
+// Winograd F(2x2,3x3) variant of a 3x3 conv (conv_wino2.hpp): `nt` channel tiles of 16 per group (1..3), `n_groups`
+// groups of which the first args.n_full hold nt tiles and the others nt - 1 (tiles are spread evenly), args.wpack in the
+// [group][chunk of 8 channels][16 f][(c & 1) * 4 + (c >> 1)][conv_ns(nt)] image -- the exact LDS image of a chunk.
+constexpr int kWinoKC = 8;
 constexpr int kWinoMaxNT = 3;
-// Filter image of the Winograd kernel: [group][chunk][16 f][kk][conv_ns(nt)], the exact LDS image of a chunk.
-constexpr int kWinoTailKC = 8;   // K chunk of the dedicated kernel for a layer's 1-tile tail group (api.hip: split_wino_tails)
-hipError_t wino_launch(int nt, int kc, const ConvArgs& a, int n_groups, hipStream_t stream);
+hipError_t wino_init_kernels();
+hipError_t wino_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
 int conv_max_fused_dw_nt();
 

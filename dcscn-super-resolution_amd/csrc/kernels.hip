@@ -15,7 +15,7 @@
 
 namespace dcscn {
 
-// ---- dispatch over the per-family translation units (conv_k1.hip, conv_k3.hip, conv_wino.hip) --------
+// ---- dispatch over the per-family translation units (conv_k1.hip, conv_k3.hip, ..., conv_wino2.hip) --------
 ConvShape conv_pick_shape(int ks, int nt, int dwk) { return ConvShape{ks, pick_mt(ks, nt), nt, pick_kc(ks, nt), dwk}; }
 size_t conv_lds_bytes(const ConvShape& s) { return lds_bytes_for(s.ks, s.mt, s.nt, s.kc, s.dwk); }
 int conv_max_fused_dw_nt() { return kMaxDwNt; }
@@ -25,7 +25,8 @@ hipError_t conv_init_kernels() {
     hipError_t e = conv_init_k1();
     if (e == hipSuccess) e = conv_init_k3();
     if (e == hipSuccess) e = conv_init_k5();
-    return e != hipSuccess ? e : conv_init_k7();
+    if (e == hipSuccess) e = conv_init_k7();
+    return e != hipSuccess ? e : wino_init_kernels();
 }
 
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream) {

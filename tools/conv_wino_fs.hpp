@@ -274,7 +274,7 @@ __device__ __forceinline__ void conv_wino_fs_body(const ConvArgs& a, float* smem
 template <int NT, int WPS>
 __global__ __launch_bounds__(256, WPS) void conv_wino_fs(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nt_valid = (blockIdx.y == gridDim.y - 1) ? a.nt_last : NT;   // block uniform
+    const int nt_valid = (blockIdx.y == gridDim.y - 1) ? a.n_full : NT;   // block uniform
     if (nt_valid == NT) conv_wino_fs_body<NT, NT>(a, smem);
     else if constexpr (NT >= 2) {
         if (nt_valid == NT - 1) conv_wino_fs_body<NT, NT - 1>(a, smem);

@@ -657,7 +657,7 @@ __device__ __forceinline__ void conv_wino_body(const ConvArgs& a, float* smem) {
 template <int NT, int KC, int WPS, bool DB = false, int ABLATE = 0, int WAVES = 4, bool DMA = false, int PRIO = 0, int PF = 0, bool VPIPE = false>
 __global__ __launch_bounds__(64 * WAVES, WPS) void conv_wino(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nt_valid = (blockIdx.y == gridDim.y - 1) ? a.nt_last : NT;   // block uniform
+    const int nt_valid = (blockIdx.y == gridDim.y - 1) ? a.n_full : NT;   // block uniform
     if constexpr (ABLATE == 7) {
         // tuner only: workgroup lifetime in shader cycles and 100 MHz ticks (wave 0)
         const long long c0 = __builtin_readcyclecounter();

@@ -1,3 +1,6 @@
+// conv_wino (r01): the register-staged Winograd kernel that shipped in round 1, kept as the timing reference of
+// tools/wino_tune.hip / tools/wino2_tune.hip.  The library now runs csrc/conv_wino2.hpp (LDS-DMA staged).
+//
 // conv_wino: 3x3 SAME convolution as Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32.
 //
 //   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A          (Lavin & Gray 2015; 16 multiplies per 2x2 outputs
@@ -28,7 +31,7 @@
 // 1.8x the direct form's (2e-4 vs 1.1e-4 on outputs of magnitude 275) and the end-to-end max-abs error of
 // the L12 network is unchanged at 1.6e-5 (dominated by the final add) -- inside the 1e-4 parity bar.
 #pragma once
-#include "conv_igemm.hpp"
+#include "../dcscn-super-resolution_amd/csrc/conv_igemm.hpp"
 
 namespace dcscn {
 
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256, WPS) void conv_wino(const ConvArgs a) {
     const int ntile = phase * S + (r >> 3);
     const int tile_id = q * 8 + (r & 7);
     if (tile_id >= a.N * a.tiles_y * a.tiles_x) return;
-    const int nt_valid = (ntile == G - 1) ? a.nt_last : NT;                // block uniform
+    const int nt_valid = (ntile == G - 1) ? a.n_full /* r01: tiles in the last group */ : NT;                // block uniform
     if (nt_valid == NT) conv_wino_body<NT, NT, KC, PF>(a, smem, tile_id, ntile);
     else if constexpr (NT >= 2) {
         if (nt_valid == NT - 1) conv_wino_body<NT, NT - 1, KC, PF>(a, smem, tile_id, ntile);

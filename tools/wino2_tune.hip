@@ -10,7 +10,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../dcscn-super-resolution_amd/csrc/conv_wino.hpp"
+#include "conv_wino_r01.hpp"
 #include "../dcscn-super-resolution_amd/csrc/conv_wino2.hpp"
 
 using namespace dcscn;
@@ -20,6 +20,9 @@ using namespace dcscn;
 #endif
 #ifndef W2_PF
 #define W2_PF 3
+#endif
+#ifndef W2_ABL
+#define W2_ABL 0
 #endif
 
 #define CK(x)                                                                              \
@@ -96,21 +99,32 @@ static std::vector<float> pack_wino1(const std::vector<float>& w, int cin, int c
     return p;
 }
 
-// conv_wino2 pack: [group][chunk of 8][f][s*4 + k][NS], channel 2k+s of the chunk in row (s, k)
-static std::vector<float> pack_wino2(const std::vector<float>& w, int cin, int cout, int cin_phys, int nt, int* n_chunks, int* n_groups, int* nt_last) {
-    const int kc = 8, ns = conv_ns(nt);
+// conv_wino2 pack (mirrors api.hip finalize_op): tiles spread evenly over ceil(tiles / 3) groups of which the first n_full
+// hold nt tiles and the others nt - 1; [group][chunk of 8][f][(c & 1) * 4 + (c >> 1)][NS]
+static void wino2_plan(int cout, int* n_groups, int* nt, int* n_full) {
     const int tiles16 = (cout + 15) / 16;
-    *n_groups = (tiles16 + nt - 1) / nt;
-    *nt_last = tiles16 - (*n_groups - 1) * nt;
+    *n_groups = (tiles16 + 2) / 3;
+    *nt = (tiles16 + *n_groups - 1) / *n_groups;
+    *n_full = tiles16 - *n_groups * (*nt - 1);
+}
+static int wino2_padded(int cc, int nt, int n_full) {
+    const int t = cc / 16, wide = n_full * nt;
+    const int g = t < wide ? t / nt : n_full + (t - wide) / (nt - 1);
+    const int tg = t < wide ? t % nt : (t - wide) % (nt - 1);
+    return (g * nt + tg) * 16 + cc % 16;
+}
+static std::vector<float> pack_wino2(const std::vector<float>& w, int cin, int cout, int cin_phys, int nt, int n_groups, int n_full, int* n_chunks) {
+    const int kc = 8, ns = conv_ns(nt);
     *n_chunks = (cin_phys + kc - 1) / kc;
     const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    std::vector<float> p((size_t)*n_groups * *n_chunks * 16 * kc * ns, 0.0f);
+    std::vector<float> p((size_t)n_groups * *n_chunks * 16 * kc * ns, 0.0f);
     for (int c = 0; c < cin; ++c)
         for (int o = 0; o < cout; ++o) {
             double g[3][3];
             for (int i = 0; i < 3; ++i)
                 for (int j = 0; j < 3; ++j) g[i][j] = w[((size_t)(i * 3 + j) * cin + c) * cout + o];
-            const int grp = o / (nt * 16), jn = o % (nt * 16);
+            const int pc = wino2_padded(o, nt, n_full);
+            const int grp = pc / (nt * 16), jn = pc % (nt * 16);
             const int cc = c % kc, row = (cc & 1) * 4 + (cc >> 1);
             for (int xi = 0; xi < 4; ++xi)
                 for (int nu = 0; nu < 4; ++nu) {
@@ -146,7 +160,7 @@ static float time_kernel(K kern, dim3 grid, size_t lds, const ConvArgs& a, int r
     return best;
 }
 
-static float *g_in, *g_ref, *g_out, *g_w, *g_bias, *g_alpha, *g_wraw;
+static float *g_in, *g_ref, *g_out, *g_w, *g_bias, *g_alpha, *g_bias2, *g_alpha2, *g_wraw;
 
 static dim3 wino_grid(ConvArgs& a, int n_groups) {
     a.n_groups = n_groups;
@@ -188,7 +202,7 @@ static Result run(const Layer& L, int N, int H, int W, int n_check, bool time_ol
         std::vector<float> p = pack_wino1(w, L.cin, L.cout, cin_phys, 3, &nch, &ng, &ntl);
         CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
         ConvArgs b = a;
-        b.wpack = g_w; b.n_chunks = nch; b.nt_last = ntl;
+        b.wpack = g_w; b.n_chunks = nch; b.n_full = ntl;      // r01 kernel: tiles in the last group
         b.out0 = OutDesc{g_out, L.out_stride, L.out_off, owidth};
         b.out1 = b.out0;
         const dim3 grid = wino_grid(b, ng);
@@ -198,19 +212,30 @@ static Result run(const Layer& L, int N, int H, int W, int n_check, bool time_ol
     }
     {
         using G2 = Wino2Geom<NT>;
-        int nch, ng, ntl;
-        std::vector<float> p = pack_wino2(w, L.cin, L.cout, cin_phys, NT, &nch, &ng, &ntl);
+        int nch, ng, nt, nfull;
+        wino2_plan(L.cout, &ng, &nt, &nfull);
+        if (nt != NT) { printf("plan mismatch\n"); exit(1); }
+        const int ntl = nfull;
+        std::vector<float> p = pack_wino2(w, L.cin, L.cout, cin_phys, NT, ng, nfull, &nch);
         CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+        {   // bias / slope in the padded layout of the plan
+            std::vector<float> bh(4096), ah(4096), bp(4096, 0.0f), ap(4096, 0.0f);
+            CK(hipMemcpy(bh.data(), g_bias, 4096 * sizeof(float), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(ah.data(), g_alpha, 4096 * sizeof(float), hipMemcpyDeviceToHost));
+            for (int o = 0; o < L.cout; ++o) { bp[wino2_padded(o, NT, nfull)] = bh[o]; ap[wino2_padded(o, NT, nfull)] = ah[o]; }
+            CK(hipMemcpy(g_bias2, bp.data(), 4096 * sizeof(float), hipMemcpyHostToDevice));
+            CK(hipMemcpy(g_alpha2, ap.data(), 4096 * sizeof(float), hipMemcpyHostToDevice));
+        }
         ConvArgs b = a;
-        b.wpack = g_w; b.n_chunks = nch; b.nt_last = ntl;
+        b.wpack = g_w; b.n_chunks = nch; b.n_full = nfull; b.bias = g_bias2; b.alpha = g_alpha2;
         b.out0 = OutDesc{g_out, L.out_stride, L.out_off, owidth};
         b.out1 = b.out0;
         const dim3 grid = wino_grid(b, ng);
-        auto kern = conv_wino2<NT, W2_WPS, W2_PF>;
+        auto kern = conv_wino2<NT, W2_WPS, W2_PF, W2_ABL>;
         const size_t lds = G2::LDS_BYTES;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CK(hipMemset(g_out, 0, out_floats * sizeof(float)));
-        r.ms_new = time_kernel(kern, grid, lds, b, time_old ? 5 : 1);
+        r.ms_new = time_kernel(kern, grid, lds, b, (time_old || W2_ABL || N > 64) ? 5 : 1);
         const size_t cnt = (size_t)n_check * H * L.ps * W * L.ps * L.out_stride;
         std::vector<float> rf(cnt), o(cnt);
         CK(hipMemcpy(rf.data(), g_ref, cnt * sizeof(float), hipMemcpyDeviceToHost));
@@ -229,12 +254,18 @@ static Result run(const Layer& L, int N, int H, int W, int n_check, bool time_ol
             for (int c = 0; c < L.out_stride; ++c)
                 if (c < L.out_off || c >= L.out_off + ((cstore + 3) & ~3)) stray = std::fmax(stray, std::fabs((double)o[px * L.out_stride + c]));
         if (!quiet || !(r.maxd < 2e-3) || stray != 0)
-            printf("%-10s %4d->%-4d %dx%dx%d ps%d NT%d groups %d (last %d) chunks %d  old %7.3f ms  new %7.3f ms %7.2f TFLOP/s(alg)  max|diff| %.3g (max|ref| %.3g)%s%s\n",
+            printf("%-10s %4d->%-4d %dx%dx%d ps%d NT%d groups %d (%d wide) chunks %d  old %7.3f ms  new %7.3f ms %7.2f TFLOP/s(alg)  max|diff| %.3g (max|ref| %.3g)%s%s\n",
                    L.name, L.cin, L.cout, N, H, W, L.ps, NT, ng, ntl, nch, r.ms_old, r.ms_new, flop / (r.ms_new * 1e-3) / 1e12, r.maxd, r.maxv,
                    r.maxd < 2e-3 ? "" : "  ** MISMATCH **", stray != 0 ? "  ** STRAY WRITE **" : "");
     }
     fflush(stdout);
     return r;
+}
+
+static Result run_layer(const Layer& L, int N, int H, int W, int n_check, bool time_old, bool quiet = false) {
+    int ng, nt, nfull;
+    wino2_plan(L.cout, &ng, &nt, &nfull);
+    return nt == 1 ? run<1>(L, N, H, W, n_check, time_old, quiet) : nt == 2 ? run<2>(L, N, H, W, n_check, time_old, quiet) : run<3>(L, N, H, W, n_check, time_old, quiet);
 }
 
 int main(int argc, char** argv) {
@@ -249,6 +280,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&g_wraw, (size_t)16 << 20));
     CK(hipMalloc(&g_bias, 4096 * sizeof(float)));
     CK(hipMalloc(&g_alpha, 4096 * sizeof(float)));
+    CK(hipMalloc(&g_bias2, 4096 * sizeof(float)));
+    CK(hipMalloc(&g_alpha2, 4096 * sizeof(float)));
     {
         std::vector<float> x = rand_vec(in_floats, 1, 2.0f);
         CK(hipMemcpy(g_in, x.data(), in_floats * sizeof(float), hipMemcpyHostToDevice));
@@ -256,7 +289,14 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(g_bias, b.data(), 4096 * sizeof(float), hipMemcpyHostToDevice));
         CK(hipMemcpy(g_alpha, al.data(), 4096 * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (!strcmp(mode, "bench")) {
+    if (!strcmp(mode, "abl")) {            // a few layers only (ablated builds give wrong results by design)
+        const Layer layers[] = {{"CNN2", 196, 166, 1316, 0, 1316, 196, 1}, {"CNN3", 166, 148, 1316, 196, 1316, 364, 1}, {"CNN4", 148, 133, 1316, 364, 1316, 512, 1},
+                                {"CNN7", 108, 97, 1316, 768, 1316, 876, 1}, {"CNN3t", 166, 16, 1316, 196, 1316, 364, 1}};
+        printf("ABL %d PF %d\n", W2_ABL, W2_PF);
+        for (const Layer& L : layers) {
+            run_layer(L, N, H, W, 1, false);
+        }
+    } else if (!strcmp(mode, "bench")) {
         // the 3x3 layers of L12_F196to48 x2 as the plan lays them out (concat stride 1316, slices at 4-channel boundaries)
         const Layer layers[] = {
             {"CNN2", 196, 166, 1316, 0, 1316, 196, 1},   {"CNN3", 166, 148, 1316, 196, 1316, 364, 1},  {"CNN4", 148, 133, 1316, 364, 1316, 512, 1},
@@ -267,7 +307,7 @@ int main(int argc, char** argv) {
         };
         double so = 0, sn = 0;
         for (const Layer& L : layers) {
-            Result r = (L.cout <= 32) ? run<2>(L, N, H, W, 2, true) : run<3>(L, N, H, W, 2, true);
+            Result r = run_layer(L, N, H, W, 2, true);
             so += r.ms_old; sn += r.ms_new;
         }
         printf("sum of 3x3 layers: old %.3f ms  new %.3f ms\n", so, sn);
@@ -275,20 +315,18 @@ int main(int argc, char** argv) {
         int bad = 0, n = 0;
         const int sizes[][2] = {{1, 1}, {2, 3}, {15, 17}, {16, 16}, {17, 33}, {31, 5}, {48, 48}, {50, 21}};
         const int cins[] = {32, 36, 40, 57, 100};
-        const int couts[] = {16, 20, 33, 48, 52, 97};
+        const int couts[] = {16, 20, 33, 48, 52, 64, 80, 97, 112, 160};
         for (auto& sz : sizes)
             for (int cin : cins)
                 for (int cout : couts) {
-                    const Layer L{"edge", cin, cout, 140, 8, 120, 4, 1};
-                    Result r1 = run<3>(L, 3, sz[0], sz[1], 3, false, true);
+                    const Layer L{"edge", cin, cout, 140, 8, 172, 4, 1};
+                    Result r1 = run_layer(L, 3, sz[0], sz[1], 3, false, true);
                     ++n; bad += !(r1.maxd < 2e-3);
-                    if (cout <= 33) { Result r2 = run<2>(L, 3, sz[0], sz[1], 3, false, true); ++n; bad += !(r2.maxd < 2e-3); }
-                    if (cout <= 20) { Result r3 = run<1>(L, 3, sz[0], sz[1], 3, false, true); ++n; bad += !(r3.maxd < 2e-3); }
                 }
         // depth_to_space epilogue (x2: 4*C channels -> C), odd image
         for (int ps : {2, 3}) {
             const Layer L{"edge-ps", 40, ps * ps * 8, 40, 0, 8, 0, ps};
-            Result r = run<3>(L, 2, 19, 23, 2, false, true);
+            Result r = run_layer(L, 2, 19, 23, 2, false, true);
             ++n; bad += !(r.maxd < 2e-3);
         }
         printf("edge: %d cases, %d mismatches\n", n, bad);

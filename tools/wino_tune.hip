@@ -8,7 +8,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../dcscn-super-resolution_amd/csrc/conv_wino.hpp"   // the shipped kernel: dcscn::conv_wino<NT, KC, WPS>
+#include "conv_wino_r01.hpp"   // the shipped kernel: dcscn::conv_wino<NT, KC, WPS>
 #include "conv_wino_fs.hpp"                                     // lab variants: dcscn_lab::...
 
 using namespace dcscn;
@@ -131,7 +131,7 @@ void run(const Layer& L) {
         int nch, ntiles, ntlast;
         std::vector<float> p = pack_wino(w, L.cin, L.cout, cin_phys, KCW, NTW, &nch, &ntiles, &ntlast);
         CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
-        a.wpack = g_w; a.n_chunks = nch; a.nt_last = ntlast;
+        a.wpack = g_w; a.n_chunks = nch; a.n_full = ntlast;
         a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gw::TH - 1) / Gw::TH;
         a.out0 = OutDesc{g_out, L.out_stride, L.out_off, (L.cout + 3) & ~3};
         a.out1 = a.out0;
@@ -251,7 +251,7 @@ void run_fs(const Layer& L) {
         int nch, ntiles, ntlast;
         std::vector<float> p = pack_wino(w, L.cin, L.cout, cin_phys, KCW, NTW, &nch, &ntiles, &ntlast);
         CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
-        a.wpack = g_w; a.n_chunks = nch; a.nt_last = ntlast;
+        a.wpack = g_w; a.n_chunks = nch; a.n_full = ntlast;
         a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gw::TH - 1) / Gw::TH;
         a.out0 = OutDesc{g_out, L.out_stride, L.out_off, (L.cout + 3) & ~3};
         a.out1 = a.out0;
@@ -371,7 +371,7 @@ void run_shipped(const Layer& L) {
         int nch, ntiles, ntlast;
         std::vector<float> p = pack_wino(w, L.cin, L.cout, cin_phys, KCW, NTW, &nch, &ntiles, &ntlast);
         CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
-        a.wpack = g_w; a.n_chunks = nch; a.nt_last = ntlast;
+        a.wpack = g_w; a.n_chunks = nch; a.n_full = ntlast;
         a.tiles_x = (W + 15) / 16; a.tiles_y = (H + Gw::TH - 1) / Gw::TH;
         a.out0 = OutDesc{g_out, L.out_stride, L.out_off, (L.cout + 3) & ~3};
         a.out1 = a.out0;
