@@ -150,7 +150,11 @@ struct dcscn_ctx {
     // LR pixels per pass through the layer chain.  Big passes keep >= ~10 rounds of workgroups per
     // launch on the 256 CUs (a 128-patch pass left a 10-25 % tail); bounded by workspace_budget.
     int64_t sub_batch_pixels = 4 << 20;
-    int64_t workspace_budget = (int64_t)48 << 30;
+    int64_t workspace_budget = (int64_t)48 << 30;   // clamped to a share of the free device memory in dcscn_create
+    bool budget_user_set = false;
+    hipEvent_t done_ev = nullptr;            // recorded behind the last forward, on the stream it ran on
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
     bool profile = false;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
     bool fold_tail = false;                  // opt-in graph rewrite, see fold_linear_tail()
@@ -898,27 +902,41 @@ int finalize_op(dcscn_ctx* h, Op& op) {
 
 // ---- workspace ---------------------------------------------------------------------------------
 
-int ensure_workspace(dcscn_ctx* h, int nb, int H, int W) {
+// (Re)carves the arena for passes of nb images of H x W.  `stream` is the stream the coming forward runs on: the clear
+// of the new carve is enqueued there, behind an event wait on the previous forward (which may have run on another
+// stream and may still be in flight) -- nothing is cleared or re-carved underneath live kernels.
+int ensure_workspace(dcscn_ctx* h, int nb, int H, int W, hipStream_t stream) {
     if (h->arena && nb <= h->lay_n && H == h->lay_h && W == h->lay_w) return DCSCN_OK;
+    std::vector<size_t> offsets(h->bufs.size());
     size_t total = 0;
-    for (WsBuf& b : h->bufs) {
-        b.offset = total;
+    for (size_t i = 0; i < h->bufs.size(); ++i) {
+        const WsBuf& b = h->bufs[i];
+        offsets[i] = total;
         const size_t bytes = (size_t)nb * H * b.res * W * b.res * b.stride * sizeof(float);
         total += (bytes + 255) & ~(size_t)255;
     }
     total = std::max<size_t>(total, 256);
     if (total > h->arena_bytes) {
+        // the old arena is freed: everything that uses it must have finished
+        if (h->has_last) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->arena) HIP_TRY(h, hipFree(h->arena));
         h->arena = nullptr;
         h->arena_bytes = 0;
+        h->lay_n = h->lay_h = h->lay_w = 0;
         hipError_t e = hipMalloc(&h->arena, total);
-        if (e != hipSuccess) return fail(h, DCSCN_ERR_NOMEM, "workspace of %zu bytes: %s", total, hipGetErrorString(e));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, DCSCN_ERR_NOMEM, "workspace of %zu bytes: %s", total, hipGetErrorString(e));
+        }
         h->arena_bytes = total;
+    } else if (h->has_last && h->last_stream != stream) {
+        HIP_TRY(h, hipStreamWaitEvent(stream, h->done_ev, 0));
     }
+    for (size_t i = 0; i < h->bufs.size(); ++i) h->bufs[i].offset = offsets[i];
     // padding channels that no kernel writes (depth_to_space outputs with C % 4 != 0) must hold
-    // finite values: clear the whole arena whenever the carve changes
-    HIP_TRY(h, hipMemsetAsync(h->arena, 0, h->arena_bytes, h->stream));
+    // finite values: clear the bytes of the new carve
+    HIP_TRY(h, hipMemsetAsync(h->arena, 0, total, stream));
     h->lay_n = nb;
     h->lay_h = H;
     h->lay_w = W;
@@ -1119,12 +1137,14 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     const int64_t budget_pixels = h->workspace_budget / std::max<int64_t>(ws_per_lr_pixel, 1);
     if (per_image > budget_pixels && h->spatial_tiling) return run_tiled(h, x, x2, y, n, H, W, budget_pixels, stream);
     int nb = (int)std::max<int64_t>(1, std::min<int64_t>(n, pass_pixels / per_image));
-    int rc = ensure_workspace(h, nb, H, W);
-    if (rc) return rc;
-    if (stream != h->stream) {
-        // order the (possible) arena clear on our stream before work on the caller's stream
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // two forwards of one handle share the arena: a forward on another stream than the previous one waits for it
+    if (h->has_last && h->last_stream != stream) HIP_TRY(h, hipStreamWaitEvent(stream, h->done_ev, 0));
+    int rc = ensure_workspace(h, nb, H, W, stream);
+    while (rc == DCSCN_ERR_NOMEM && nb > 1) {            // less free memory than the budget assumed: smaller passes
+        nb = (nb + 1) / 2;
+        rc = ensure_workspace(h, nb, H, W, stream);
     }
+    if (rc) return rc;
     const int s = h->cfg.scale;
     const int batches = (n + nb - 1) / nb;
     const int nops = (int)h->ops.size();
@@ -1154,6 +1174,9 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
             if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[ev_base + ((size_t)b * nops + i) * 2 + 1], stream));
         }
     }
+    HIP_TRY(h, hipEventRecord(h->done_ev, stream));
+    h->last_stream = stream;
+    h->has_last = true;
     return DCSCN_OK;
 }
 
@@ -1291,7 +1314,13 @@ int dcscn_create(const dcscn_config* cfg, int device, dcscn_handle* out) {
             break;
         }
         if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(h, DCSCN_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
+        if ((e = hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming)) != hipSuccess) { rc = fail(h, DCSCN_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)); break; }
         if ((e = conv_init_kernels()) != hipSuccess) { rc = fail(h, DCSCN_ERR_HIP, "kernel attribute setup: %s", hipGetErrorString(e)); break; }
+        {   // default workspace budget: at most 60 % of what is free now (other ranks may share the device)
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
+                h->workspace_budget = std::min<int64_t>(h->workspace_budget, std::max<int64_t>((int64_t)(free_b / 10 * 6), (int64_t)256 << 20));
+        }
         rc = build_graph(h);
     } while (0);
     if (rc != DCSCN_OK) {
@@ -1408,6 +1437,7 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "workspace_budget_bytes")) {
         if (value < 1) return fail(h, DCSCN_ERR_INVALID_ARG, "workspace_budget_bytes must be >= 1");
         h->workspace_budget = value;
+        h->budget_user_set = true;
         return DCSCN_OK;
     }
     if (!strcmp(key, "spatial_tiling")) {
@@ -1607,10 +1637,27 @@ int64_t dcscn_workspace_bytes(dcscn_handle h) { return h ? (int64_t)h->arena_byt
 
 const char* dcscn_last_error(dcscn_handle h) { return h ? h->error.c_str() : g_global_error.c_str(); }
 
+int dcscn_get_stream(dcscn_handle h, void** stream) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!stream) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_get_stream: null pointer");
+    *stream = (void*)h->stream;
+    return DCSCN_OK;
+}
+
+int dcscn_synchronize(dcscn_handle h) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->has_last) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return DCSCN_OK;
+}
+
 int dcscn_destroy(dcscn_handle h) {
     if (!h) return DCSCN_OK;
     (void)hipSetDevice(h->device);
+    if (h->has_last) (void)hipStreamSynchronize(h->last_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->done_ev) (void)hipEventDestroy(h->done_ev);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (void* p : h->device_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "dcscn_layer_info_get", "dcscn_num_ops", "dcscn_op_info_get", "dcscn_set_option", "dcscn_forward",
     "dcscn_forward_device", "dcscn_forward_ensemble", "dcscn_get_profile", "dcscn_workspace_bytes",
     "dcscn_last_error", "dcscn_destroy", "dcscn_resize_bicubic", "dcscn_resize_bicubic_device", "dcscn_forward_lr",
-    "dcscn_resample_table",
+    "dcscn_resample_table", "dcscn_get_stream", "dcscn_synchronize",
 )
 
 
@@ -139,6 +139,8 @@ def load_library():
     lib.dcscn_resample_table.argtypes = [c.c_int, c.c_int, c.POINTER(c.c_int), c.POINTER(c.c_int), dp, c.c_int]
     lib.dcscn_get_profile.argtypes = [vp, dp, c.c_int]
     lib.dcscn_workspace_bytes.argtypes = [vp]
+    lib.dcscn_get_stream.argtypes = [vp, c.POINTER(vp)]
+    lib.dcscn_synchronize.argtypes = [vp]
     lib.dcscn_workspace_bytes.restype = c.c_int64
     lib.dcscn_last_error.argtypes = [vp]
     lib.dcscn_last_error.restype = c.c_char_p
@@ -353,8 +355,21 @@ class Engine:
                                                    int(out_height), int(out_width)))
         return out[0] if single else out
 
+    def stream(self):
+        """The handle's own hipStream_t as an int (non-blocking: not ordered against the legacy default stream)."""
+        out = ctypes.c_void_p()
+        self._check(self._lib.dcscn_get_stream(self._h, ctypes.byref(out)))
+        return int(out.value or 0)
+
+    def synchronize(self):
+        """Wait for everything enqueued through this handle (whatever stream it ran on)."""
+        self._check(self._lib.dcscn_synchronize(self._h))
+
     def forward_device(self, x_ptr, x2_ptr, y_ptr, n, h, w, stream=None):
-        """Enqueue on device pointers (ints, e.g. ``torch.Tensor.data_ptr()``); does not synchronise."""
+        """Enqueue on device pointers (ints, e.g. ``torch.Tensor.data_ptr()``); does not synchronise.
+
+        ``stream``: a hipStream_t as an int; None / 0 means the handle's OWN stream (``self.stream()``), which is not
+        ordered against the caller's default stream -- order with ``synchronize()`` or events, or pass a real stream."""
         self._check(self._lib.dcscn_forward_device(self._h, ctypes.c_void_p(x_ptr), ctypes.c_void_p(x2_ptr),
                                                    ctypes.c_void_p(y_ptr), n, h, w,
                                                    ctypes.c_void_p(stream) if stream else None))

@@ -263,7 +263,9 @@ class SuperResolution:
         ch = input_image.shape[2] if len(input_image.shape) > 2 else 1
         if ch != 1:
             raise ValueError("do() expects a single-channel image, got %d channels" % ch)
-        if bicubic_input_image is None and self.resampling_method == "bicubic":
+        # the device bicubic reproduces Pillow's mode-'F' path (float images).  A uint8 single-channel image goes through
+        # Pillow's mode 'L' in the reference (utilty.py:229-232: rounded and clipped to 0..255), so it stays on the host
+        if bicubic_input_image is None and self.resampling_method == "bicubic" and np.issubdtype(np.asarray(input_image).dtype, np.floating):
             # DCSCN.py:552-554 on the device: dcscn_resize_bicubic is bit-compatible with Pillow's mode-'F' BICUBIC
             # (tests/test_resize_hip.py), so x2 never has to be built or uploaded by the host
             eng = self._ready_engine()

@@ -33,7 +33,7 @@ _TABLE = [
     (_I, "reconstruct_filters", 32, "filters of the extra reconstruction layers"),
     (_F, "dropout_rate", 0.8, "keep probability while training; inference always keeps everything"),
     (_S, "activator", "prelu", "relu, leaky_relu, prelu, sigmoid, tanh or selu"),
-    (_B, "pixel_shuffler", True, "pixel-shuffler upsampling (the transposed-conv variant is not implemented)"),
+    (_B, "pixel_shuffler", True, "pixel-shuffler upsampling; false = transposed-conv upsampler (Up-TCNN, tf_graph.py:219-236)"),
     (_I, "pixel_shuffler_filters", 0, "pixel-shuffler output channels, 0 = as many as its input"),
     (_I, "self_ensemble", 8, "flipped / rotated copies averaged per image, 1 to 8"),
     (_B, "batch_norm", False, "batch normalisation (not implemented)"),

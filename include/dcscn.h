@@ -183,9 +183,20 @@ int dcscn_resize_bicubic_device(dcscn_handle h, const float* in, float* out, int
 int dcscn_forward_lr(dcscn_handle h, const float* x, float* y, int n, int height, int width);
 
 /* Forward pass on device buffers, enqueued on `stream` (a hipStream_t, NULL = the handle's own
- * stream) without synchronising.  Workspace growth (first call / larger shape) does synchronise. */
+ * stream, see dcscn_get_stream) without synchronising.  Workspace growth (first call / larger shape) does
+ * synchronise.  Consecutive calls on DIFFERENT streams are ordered by the library (they share the workspace): the
+ * later call waits, on the device, for the earlier one.  The reference analogue is a second sess.run on the same
+ * session (DCSCN.py:565-569): it simply runs after the first. */
 int dcscn_forward_device(dcscn_handle h, const float* x, const float* x2, float* y,
                          int n, int height, int width, void* stream);
+
+/* The handle's own hipStream_t (created non-blocking: it does NOT synchronise with the legacy default stream), so a
+ * caller that passes stream = NULL above can order its own work against it (hipStreamWaitEvent / hipStreamSynchronize). */
+int dcscn_get_stream(dcscn_handle h, void** stream);
+
+/* Blocks until every forward / resize enqueued through this handle has finished, whatever stream it ran on
+ * (sess.run is synchronous; this is the explicit form for the _device entry points). */
+int dcscn_synchronize(dcscn_handle h);
 
 /* do() with self_ensemble = n_ensemble in [1, 8] for ONE image (DCSCN.py:559-573): the flipped /
  * rotated copies (utilty.py:595-617) run as two batches on the device; the mean over copies is

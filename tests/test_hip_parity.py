@@ -308,3 +308,31 @@ def test_spatial_tiling_window_too_small(oracle):
         eng.set_option("workspace_budget_bytes", 1)
         with pytest.raises(engine.EngineError):
             eng.forward(x, x2)
+
+
+def test_forward_device_alternating_shapes_and_streams(oracle):
+    """two shapes alternate through dcscn_forward_device on user streams with no sync in between.  The
+    second shape fits the arena of the first, so the re-carve neither frees nor synchronises; the library must
+    order its clear (and the forward) behind the previous call -- every output must still match a fresh run."""
+    torch = pytest.importorskip("torch")
+    cfg = oracle.make_config(**CONFIGS["L7_F32to8_x2"])
+    weights = oracle.synthetic_weights(cfg, seed=3)
+    shapes = [(6, 48, 40), (3, 24, 56)]
+    data = [synthetic_batch(n, h, w, 2, seed=20 + i) for i, (n, h, w) in enumerate(shapes)]
+    with _engine(cfg, weights) as eng:
+        expect = [eng.forward(x, x2) for x, x2 in data]
+        dev = [(torch.from_numpy(x).cuda(), torch.from_numpy(x2).cuda()) for x, x2 in data]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = []
+        torch.cuda.synchronize()
+        for it in range(8):
+            k = it & 1
+            xd, x2d = dev[k]
+            y = torch.empty_like(x2d)
+            n, h, w = shapes[k]
+            eng.forward_device(xd.data_ptr(), x2d.data_ptr(), y.data_ptr(), n, h, w, stream=streams[(it // 2) & 1].cuda_stream)
+            outs.append((k, y))
+        eng.synchronize()
+        for k, y in outs:
+            assert np.array_equal(y.cpu().numpy(), expect[k]), "output of an un-synchronised call differs"
+        assert eng.stream() != 0
