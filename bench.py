@@ -6,14 +6,22 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the default
-``dcscn_L12_F196to48_NIN_A64_PS`` x2 graph on 1024 synthetic 48x48 Y-channel patches PER GPU
-(weak scaling: independent patches shard across ranks, no data-path collective).  A step is one
-forward pass of the whole per-GPU batch with x / x2 already resident in HBM and y left in HBM.
-Weights are seeded synthetic (the trained L12 blobs are not shipped with the reference).
+``dcscn_L12_F196to48_NIN_A64_PS`` x2 graph on synthetic 48x48 Y-channel patches -- 1024 PER GPU (weak
+scaling, the default) or, with ``--strong``, 1024 in total split into contiguous shards of 1024 / N per
+rank (512 / 256 / 128 per GPU at 2 / 4 / 8).  Independent patches shard across ranks with
+no data-path collective.  A step is one forward pass of the rank's whole batch with x / x2 already
+resident in HBM and y left in HBM.  Weights are seeded synthetic (the trained L12 blobs are not shipped).
+The graph executed is the library default (linear tail folded into one 5x5 conv, include/dcscn.h
+"fold_linear_tail"); the layer-by-layer graph is timed beside it at N = 1 (``layer_by_layer``).
 
 Rank 0 prints one JSON line: LR Mpixels/s over all GPUs, plus
-  roofline      -- the dominant kernel (3x3 implicit-GEMM conv on f32 MFMA): algorithmic FLOP per
-                   step / its summed launch time measured with HIP events inside the timed steps
+  roofline      -- the dominant kernel (conv_wino2, the 3x3 convs on f32 MFMA): `achieved` = the FLOPs the
+                   kernel really issues per step / its summed launch time, measured with HIP events on the
+                   launch stream inside the timed steps; `frac` = achieved / f32 MFMA peak = matrix-pipe
+                   utilisation (<= 1).  The direct-form (algorithmic) FLOP rate of the same launches is
+                   reported separately (`algorithmic_tflops`, `algorithmic_speedup_vs_direct_peak`).
+                   `traffic` is REPLAYED from the committed rocprofv3 PMC passes of this command
+                   (profiles/r*_pmc_per_dispatch.json): PMC counters cannot be read in-process.
   cpu_baseline  -- the float32 torch-CPU restatement of the same graph (oracle/cpu_path_torch.py;
                    TensorFlow is not installable) timed on the host cores on a bounded sample.
 """
@@ -37,54 +45,60 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dens
 PEAK_HBM_GBS = 8000.0
 
 
-def pmc_north_star(dom_ms, nin_ms):
-    """The two figures BASELINE.json's north_star names, from the committed PMC passes + this run's kernel times:
-    HBM GB/s on the 3x3 feature stack (vs 8 TB/s) and matrix-pipe utilisation of the 1x1 NIN GEMM."""
+def _pmc_file():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_dispatch.json")))
-    if not files:
-        return None
+    return files[-1] if files else None
+
+
+def pmc_replay(dom_ms, nin_ms, algorithmic_bytes):
+    """REPLAYED (not measured in this run): figures from the committed rocprofv3 PMC passes of this same command
+    (tools/rocprof_bench.sh -> profiles/r*_pmc_per_dispatch.json), combined with this run's kernel times.
+    Returns (traffic, north_star).  traffic: HBM bytes per step of the dominant kernel, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950 (the counter tallies 128-B requests at
+    64 B), WRITE_SIZE as reported."""
+    path = _pmc_file()
+    if not path:
+        return None, None
     try:
-        with open(files[-1]) as f:
-            kernels = json.load(f)["kernels"]
-        out = {"source": os.path.basename(files[-1])}
-        tr = pmc_traffic(0)
-        if tr and dom_ms > 0:
-            gbs = tr["bytes_per_step"] / (dom_ms * 1e-3) / 1e9
-            out["hbm_3x3_stack"] = {"achieved_GBps": round(gbs, 1), "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                    "note": "the 3x3 stack is a dense f32 contraction (AI 117-404 FLOP/B): MFMA bound, not HBM bound"}
+        with open(path) as f:
+            doc = json.load(f)
+        kernels = doc["kernels"]
+        fetch = write = 0.0
+        for name, k in kernels.items():
+            if name.startswith("conv_wino") and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+                per_forward = k["dispatches"] / max(k.get("forwards", 4), 1)
+                fetch += k["FETCH_SIZE"] * 1024.0 * per_forward
+                write += k["WRITE_SIZE"] * 1024.0 * per_forward
+        traffic = None
+        if fetch:
+            corrected = 2.0 * fetch + write
+            traffic = {"bytes_per_step": corrected, "replayed": True, "source": os.path.basename(path),
+                       "fetch_bytes_reported": fetch, "write_bytes_reported": write,
+                       "correction": "FETCH_SIZE x 2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE as reported",
+                       "algorithmic_bytes_per_step": algorithmic_bytes,
+                       "traffic_ratio": round(corrected / algorithmic_bytes, 3) if algorithmic_bytes else None}
+        ns = {"replayed": True, "source": os.path.basename(path)}
+        if traffic and dom_ms > 0:
+            gbs = traffic["bytes_per_step"] / (dom_ms * 1e-3) / 1e9
+            ns["hbm_3x3_stack"] = {"achieved_GBps": round(gbs, 1), "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                   "note": "counter bytes (corrected) / this run's kernel time; the 3x3 stack is a dense f32 "
+                                           "contraction (AI 117-404 FLOP/B): MFMA bound, not HBM bound"}
         for name, k in kernels.items():
             if name.startswith("conv_igemm<1,") and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
                 active = k["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
-                out["nin_1x1"] = {"mfma_util": round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * active), 4),
-                                  "ms_per_step": round(nin_ms, 4),
-                                  "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x active cycles), fused B1+A1 GEMM"}
-        return out
+                ns["nin_1x1"] = {"mfma_util": round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * active), 4),
+                                 "ms_per_step": round(nin_ms, 4),
+                                 "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x active cycles), fused B1+A1 GEMM"}
+            if name.startswith("conv_wino") and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
+                active = k["GRBM_GUI_ACTIVE"] / 8.0
+                ns.setdefault("wino_3x3", {})[name] = {
+                    "mfma_util": round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * active), 4),
+                    "lds_bank_conflict_frac": round(k["SQ_LDS_BANK_CONFLICT"] / k["SQ_LDS_IDX_ACTIVE"], 4)
+                    if k.get("SQ_LDS_IDX_ACTIVE") else None}
+        return traffic, ns
     except (OSError, KeyError, ValueError, ZeroDivisionError):
-        return None
-
-
-def pmc_traffic(n_launches):
-    """HBM bytes per step of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/*_pmc_per_dispatch.json: FETCH_SIZE + WRITE_SIZE, KiB, summed over the 3x3
-    conv_igemm dispatches of one forward).  PMC counters cannot be read from inside the process, so
-    this is the offline measurement; None when no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_dispatch.json")))
-    if not files:
-        return None
-    try:
-        with open(files[-1]) as f:
-            kernels = json.load(f)["kernels"]
-        total = 0.0
-        for name, k in kernels.items():
-            if (name.startswith("conv_igemm<3,") or name.startswith("conv_wino")) and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
-                per_forward = k["dispatches"] / max(k.get("forwards", 4), 1)
-                total += (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 * per_forward
-        return {"bytes_per_step": total, "unit": "B", "source": os.path.basename(files[-1]),
-                "note": "FETCH_SIZE+WRITE_SIZE as reported by rocprofv3 (uncalibrated on gfx950)"} if total else None
-    except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def parse_args():
@@ -99,9 +113,15 @@ def parse_args():
     ap.add_argument("--no-winograd", action="store_true", help="keep the 3x3 convs on the direct implicit-GEMM kernel")
     ap.add_argument("--cpu-sample", type=int, default=64, help="patches in the CPU baseline sample")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive timing of the host-buffer entry points")
-    ap.add_argument("--no-opt-in", action="store_true", help="skip the extra timing of the opt-in folded tail")
-    ap.add_argument("--fold-tail", action="store_true",
-                    help="opt into the folded linear tail (include/dcscn.h: fold_linear_tail); the default runs the reference's layers one by one")
+    ap.add_argument("--no-opt-in", "--no-layer-by-layer", dest="no_extra_graph", action="store_true",
+                    help="skip the extra timing of the layer-by-layer graph")
+    ap.add_argument("--layer-by-layer", action="store_true",
+                    help="headline on the reference's layers one by one (fold_linear_tail = 0) instead of the library default")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --patches is the GLOBAL batch, split into contiguous shards over the ranks")
+    ap.add_argument("--check-output", action="store_true",
+                    help="after the timed steps, hash every output patch (sha256) and report the digest of the global batch "
+                         "in patch order: equal for any number of ranks with --strong (tests/test_multi_rank_gpu.py)")
     return ap.parse_args()
 
 
@@ -138,17 +158,35 @@ def main():
     cfg = O.make_config(**MODEL_FLAGS)
     weights = O.synthetic_weights(cfg, seed=0)
     eng = engine.Engine(cfg, device=device_index)
-    eng.load_weights(weights, winograd=False if args.no_winograd else None, fold_tail=True if args.fold_tail else None)
+    eng.load_weights(weights, winograd=False if args.no_winograd else None, fold_tail=False if args.layer_by_layer else None)
     if args.sub_batch_pixels:
         eng.set_option("sub_batch_pixels", args.sub_batch_pixels)
+    folded = any("(folded)" in o["name"] for o in eng.ops())
 
-    n, s = args.patches, cfg["scale"]
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
-    x = torch.rand((n, PATCH, PATCH, 1), device="cuda", generator=gen) * 255.0
-    x2 = torch.rand((n, PATCH * s, PATCH * s, 1), device="cuda", generator=gen) * 255.0
+    s = cfg["scale"]
+    if args.strong:
+        # the same global batch on every rank (seeded on the CPU so that it does not depend on the rank count),
+        # contiguous shard [lo, hi) of it on this rank (dcscn-super-resolution_amd/shard.py)
+        from dcscn_amd import shard
+        lo, hi = shard.shard_bounds(args.patches, rank, world)
+        n = hi - lo
+        gcpu = torch.Generator(device="cpu")
+        gcpu.manual_seed(1234)
+        xg = torch.rand((args.patches, PATCH, PATCH, 1), generator=gcpu) * 255.0
+        x2g = torch.rand((args.patches, PATCH * s, PATCH * s, 1), generator=gcpu) * 255.0
+        x, x2 = xg[lo:hi].cuda(), x2g[lo:hi].cuda()
+        del xg, x2g
+    else:
+        n = args.patches
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(1234 + rank)
+        x = torch.rand((n, PATCH, PATCH, 1), device="cuda", generator=gen) * 255.0
+        x2 = torch.rand((n, PATCH * s, PATCH * s, 1), device="cuda", generator=gen) * 255.0
     y = torch.empty_like(x2)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a real (non-default) stream of our own: stream 0 / NULL would mean "the handle's own stream" to the C ABI
+    tstream = torch.cuda.Stream()
+    stream = tstream.cuda_stream
+    torch.cuda.synchronize()          # inputs were produced on the default stream
 
     def step():
         eng.forward_device(x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, PATCH, PATCH, stream)
@@ -174,79 +212,102 @@ def main():
         t = torch.tensor([elapsed], device="cpu" if share_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if not bool(torch.isfinite(y).all().item()):
+    if n and not bool(torch.isfinite(y).all().item()):
         raise SystemExit("non-finite output")
+    digest = None
+    if args.check_output:
+        import hashlib
+        yh = y.cpu().numpy()
+        mine = [hashlib.sha256(yh[i].tobytes()).hexdigest() for i in range(n)]
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, mine)
+            mine = [d for p in parts for d in p]       # rank order == patch order (contiguous shards)
+        digest = hashlib.sha256("".join(mine).encode()).hexdigest()
+    global_patches = args.patches if args.strong else n * world
 
     if rank == 0:
         ops = eng.ops()
-        lr_pixels = n * PATCH * PATCH
-        # dominant kernel: the 3x3 implicit-GEMM conv launches (CNN2..12, B2, Up-PS)
-        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino", "conv_wino2")
+        lr_pixels = n * PATCH * PATCH                         # this rank's
+        global_lr_pixels = global_patches * PATCH * PATCH
+        # dominant kernel: the Winograd 3x3 launches (CNN2..12, B2, and Up-PS in the layer-by-layer graph)
+        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino2")
                and o["kernel_size"] == 3 and o["out_channels"] > 1]
         dom_kernels = sorted({o["kernel"] for o, _ in dom})
         dom_flop = sum(2.0 * o["macs_per_lr_pixel"] for o, _ in dom) * lr_pixels
+        dom_bytes = sum(float(o["bytes_per_lr_pixel"]) for o, _ in dom) * lr_pixels
         dom_ms = sum(ms for _, ms in dom)
-        achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        algorithmic = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         dom_exec = sum(2.0 * o["executed_macs_per_lr_pixel"] for o, _ in dom) * lr_pixels
         executed = dom_exec / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         total_macs = sum(o["macs_per_lr_pixel"] for o in ops)
         kernel_ms = sum(per_op_ms)
         per_kernel = {}
         for o, ms in zip(ops, per_op_ms):
-            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] in ("conv_igemm", "conv_wino", "conv_wino2") else "")
+            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] in ("conv_igemm", "conv_wino2") else "")
             per_kernel[key] = per_kernel.get(key, 0.0) + ms
         if args.ops:
             for o, ms in zip(ops, per_op_ms):
                 fl = 2.0 * o["macs_per_lr_pixel"] * lr_pixels
+                fx = 2.0 * o["executed_macs_per_lr_pixel"] * lr_pixels
                 by = o["bytes_per_lr_pixel"] * lr_pixels
-                print("%-22s %-11s k%d %4d->%-4d res%d mt%d nt%-2d kc%-2d tiles%d  %8.3f ms  %7.2f TFLOP/s  %7.1f GB/s"
+                print("%-22s %-11s k%d %4d->%-4d res%d mt%d nt%-2d kc%-2d tiles%d  %8.3f ms  %7.2f TFLOP/s (alg)  %7.2f TFLOP/s (exec)  %7.1f GB/s"
                       % (o["name"], o["kernel"], o["kernel_size"], o["in_channels"], o["out_channels"], o["resolution"],
                          o["mt"], o["nt"], o["kc"], o["n_tiles"], ms, fl / (ms * 1e-3) / 1e12 if ms else 0,
-                         by / (ms * 1e-3) / 1e9 if ms else 0), file=sys.stderr)
+                         fx / (ms * 1e-3) / 1e12 if ms else 0, by / (ms * 1e-3) / 1e9 if ms else 0), file=sys.stderr)
+        nin_ms = sum(ms for o, ms in zip(ops, per_op_ms) if o["kernel"] == "conv_igemm" and o["kernel_size"] == 1)
+        full_workload = n == PATCHES_PER_GPU and not args.no_winograd
+        traffic, north_star = pmc_replay(dom_ms, nin_ms, dom_bytes) if full_workload else (None, None)
+        graph = ("linear tail (Up-PS conv + depth_to_space + R-CNN1) folded into one 5x5 conv -- library default, include/dcscn.h fold_linear_tail"
+                 if folded else "the reference's layers, one launch per layer (B1+A1 share a launch)")
         result = {
             "metric": "LR Mpixels/sec at 48x48 patches, L12_F196to48 x2",
-            "value": round(world * lr_pixels * args.steps / elapsed / 1e6, 4),
+            "value": round(global_lr_pixels * args.steps / elapsed / 1e6, 4),
             "unit": "LR Mpix/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (uniform 0-255 Y patches, seeded He-init weights; trained L12 blobs are not shipped)",
             "config": {
-                "workload": "%s x2 forward, %d 48x48 Y patches per GPU (BASELINE.json configs[2])" % (MODEL_NAME, n),
+                "workload": "%s x2 forward, %s (BASELINE.json configs[2])" % (
+                    MODEL_NAME, ("%d 48x48 Y patches in total, %d on rank 0" % (global_patches, n)) if args.strong
+                    else "%d 48x48 Y patches per GPU" % n),
                 "patches_per_gpu": n,
-                "global_patches": n * world,
+                "global_patches": global_patches,
                 "parallelism": "image-shard x%d, no collective" % world,
                 "flop_per_lr_pixel": 2 * total_macs,
-                "graph": "linear tail folded into one 5x5 conv (opt-in rewrite, include/dcscn.h fold_linear_tail)"
-                         if args.fold_tail else "the reference's layers, one launch per layer (B1+A1 share a launch)",
+                "graph": graph,
             },
             "roofline": {
                 "kernel": "%s 3x3 (v_mfma_f32_16x16x4_f32), %d launches/pass" % ("+".join(dom_kernels), len(dom)),
                 "bound": "mfma",
-                "achieved": round(achieved, 3),
+                "achieved": round(executed, 3),
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": pmc_traffic(len(dom)) if n == PATCHES_PER_GPU else None,
-                "algorithmic_flop_per_step": dom_flop,
+                "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": traffic["bytes_per_step"] if traffic else None,
+                "traffic_detail": traffic,
                 "executed_flop_per_step": dom_exec,
-                "executed_tflops": round(executed, 3),
-                "mfma_pipe_util": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
-                "note": "achieved counts the direct-form FLOPs of the conv; the Winograd F(2x2,3x3) kernel issues 16/36 "
-                        "of them (plus channel padding), so frac can exceed 1 while the MFMA pipe runs at mfma_pipe_util",
+                "algorithmic_flop_per_step": dom_flop,
+                "algorithmic_tflops": round(algorithmic, 3),
+                "algorithmic_speedup_vs_direct_peak": round(algorithmic / PEAK_F32_MFMA_TFLOPS, 4),
+                "note": "achieved = FLOPs the kernel issues (Winograd F(2x2,3x3): 16/36 of the direct form, plus channel padding "
+                        "to 16 / 8) per second of its own launch time (HIP events on the launch stream); frac = matrix-pipe "
+                        "utilisation.  algorithmic_* count the direct-form FLOPs of SURVEY.md 8(d) for the same launches.",
                 "kernel_ms_per_step": round(dom_ms, 4),
             },
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_kernel.items())},
             "whole_net_tflops": round(2.0 * total_macs * lr_pixels / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms else None,
         }
-        if n == PATCHES_PER_GPU and not args.fold_tail:
-            nin_ms = sum(ms for o, ms in zip(ops, per_op_ms) if o["kernel"] == "conv_igemm" and o["kernel_size"] == 1)
-            result["north_star"] = pmc_north_star(dom_ms, nin_ms)
+        if digest is not None:
+            result["output_sha256"] = digest
+        if north_star:
+            result["north_star"] = north_star
         if world == 1 and not args.no_cpu_baseline:
             import cpu_path_torch as T
             cs = min(args.cpu_sample, n)
@@ -259,8 +320,9 @@ def main():
                 "unit": "LR Mpix/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": "%d of the %d patches, float32 torch-CPU (oneDNN) restatement of the reference graph "
-                          "(TensorFlow not installable), best of 2 after 1 warm-up per thread setting, %.2f s/forward" % (cs, n, sec),
+                "sample": "%d of the %d patches, float32 torch-CPU (oneDNN, NCHW, untuned: a few %% of the host's f32 peak) "
+                          "restatement of the reference graph (TensorFlow not installable), best of 2 after 1 warm-up per thread "
+                          "setting, %.2f s/forward" % (cs, n, sec),
                 "max_abs_diff_vs_hip": dev_err,
             }
         if world == 1 and not args.no_host_path:
@@ -288,32 +350,31 @@ def main():
                 }
             except Exception as exc:
                 result["host_path"] = {"error": str(exc)}
-        if world == 1 and not args.fold_tail and not args.no_opt_in:
-            # reported beside the headline, never as `value`: the opt-in graph rewrite (same function, fewer
-            # FLOPs), timed the same way on the same inputs
+        if world == 1 and folded and not args.no_extra_graph:
+            # beside the headline: the same inputs through the layer-by-layer graph (fold_linear_tail = 0), timed the same way
             try:
                 y_ref = y.clone()
                 eng2 = engine.Engine(cfg, device=device_index)
-                eng2.load_weights(weights, winograd=False if args.no_winograd else None, fold_tail=True)
+                eng2.load_weights(weights, winograd=False if args.no_winograd else None, fold_tail=False)
                 if args.sub_batch_pixels:
                     eng2.set_option("sub_batch_pixels", args.sub_batch_pixels)
                 for _ in range(max(args.warmup, 1)):
                     eng2.forward_device(x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, PATCH, PATCH, stream)
-                torch.cuda.synchronize()
+                eng2.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(args.steps):
                     eng2.forward_device(x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, PATCH, PATCH, stream)
-                torch.cuda.synchronize()
+                eng2.synchronize()
                 el2 = time.perf_counter() - t1
-                result["opt_in"] = {"fold_linear_tail": {
+                result["layer_by_layer"] = {
                     "value": round(lr_pixels * args.steps / el2 / 1e6, 4), "unit": "LR Mpix/s",
                     "ms_per_step": round(el2 / args.steps * 1e3, 4),
-                    "max_abs_diff_vs_layer_by_layer": float((y - y_ref).abs().max().item()),
-                    "note": "Up-PS conv + depth_to_space + R-CNN1 as one 5x5 conv; not the headline value",
-                }}
+                    "max_abs_diff_vs_default_graph": float((y - y_ref).abs().max().item()),
+                    "note": "fold_linear_tail = 0: Up-PS conv, depth_to_space and R-CNN1 as separate launches (the reference's graph)",
+                }
                 eng2.close()
             except Exception as exc:      # the headline line must survive a failure of the extra leg
-                result["opt_in"] = {"fold_linear_tail": {"error": str(exc)}}
+                result["layer_by_layer"] = {"error": str(exc)}
         print(json.dumps(result), flush=True)
 
     eng.close()

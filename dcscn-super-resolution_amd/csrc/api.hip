@@ -157,7 +157,7 @@ struct dcscn_ctx {
     bool has_last = false;
     bool profile = false;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
-    bool fold_tail = false;                  // opt-in graph rewrite, see fold_linear_tail()
+    bool fold_tail = true;                   // graph rewrite of the linear tail, see fold_linear_tail(); option "fold_linear_tail" 0 = layer by layer
     bool spatial_tiling = true;              // images larger than one pass are cut into haloed windows (run_tiled)
     std::vector<hipEvent_t> ev;              // event pool: 2 per launch
     size_t ev_used = 0;                      // events recorded since the last dcscn_get_profile

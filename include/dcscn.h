@@ -153,11 +153,12 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * lets the allocation fail instead), "profile" (1: time every launch with HIP events, read back with dcscn_get_profile),
  * "winograd" (default 1; before dcscn_finalize only: 0 keeps every 3x3 conv on the direct
  * implicit-GEMM kernel instead of the Winograd F(2x2,3x3) kernel),
- * "fold_linear_tail" (default 0; before dcscn_finalize only: 1 runs the last pixel-shuffler conv,
- * depth_to_space and the last reconstruction conv -- all linear, DCSCN.py:293-323 -- as ONE 5x5 conv of
- * the low-resolution map with per-phase / per-border kernels composed in float64; same function, f32
- * results differ by re-association only; ignored where the graph has no such tail: separable convs,
- * transposed-conv upsampler, reconstruct_layers > 1, cnn_size != 3). */
+ * "fold_linear_tail" (default 1; before dcscn_finalize only): the last pixel-shuffler conv, depth_to_space and the last
+ * reconstruction conv -- all linear, no activator between them, DCSCN.py:293-323 -- run as ONE 5x5 conv of the
+ * low-resolution map with per-phase / per-border kernels composed in float64 from the checkpoint tensors; the same
+ * function, f32 results differ from the layer-by-layer graph by re-association only (parity-tested against the float64
+ * oracle at the same 1e-4 bar).  0 = the escape hatch: execute the reference's layers one by one.  Ignored where the
+ * graph has no such tail: separable convs, transposed-conv upsampler, reconstruct_layers > 1, cnn_size != 3. */
 int dcscn_set_option(dcscn_handle h, const char* key, int64_t value);
 
 /* Forward pass on host buffers: H2D, kernels, D2H, synchronous. */
