@@ -142,6 +142,9 @@ struct dcscn_ctx {
     float* ens_x = nullptr; float* ens_x2 = nullptr; float* ens_y = nullptr; float* ens_out = nullptr;
     size_t ens_x_cap = 0, ens_x2_cap = 0, ens_y_cap = 0, ens_out_cap = 0;
     float* rs_in = nullptr; float* rs_out = nullptr; size_t rs_in_cap = 0, rs_out_cap = 0;
+    // colour path (color.hip): uint8 RGB in, float64 planes, float32 Y; capacities in floats
+    float* col_rgb = nullptr; float* col_d = nullptr; float* col_d2 = nullptr; float* col_y32 = nullptr;
+    size_t col_rgb_cap = 0, col_d_cap = 0, col_d2_cap = 0, col_y32_cap = 0;
     // spatial tiling of images larger than one pass (run_tiled): gathered tile batch
     float* tile_x = nullptr; float* tile_x2 = nullptr; float* tile_y = nullptr;
     size_t tile_x_cap = 0, tile_y_cap = 0;
@@ -1576,25 +1579,16 @@ int dcscn_forward_lr(dcscn_handle h, const float* x, float* y, int n, int height
     return DCSCN_OK;
 }
 
-int dcscn_forward_ensemble(dcscn_handle h, const float* x, const float* x2, double* y, int height, int width, int n_ensemble) {
-    if (!h) return DCSCN_ERR_INVALID_ARG;
-    if (!h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_forward_ensemble before dcscn_finalize");
-    if (!x || !x2 || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
-    if (n_ensemble < 1 || n_ensemble > 8) return fail(h, DCSCN_ERR_INVALID_ARG, "n_ensemble %d outside [1, 8]", n_ensemble);
-    if (height <= 0 || width <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape h=%d w=%d", height, width);
-    HIP_TRY(h, hipSetDevice(h->device));
-    const int s = h->cfg.scale, n = n_ensemble;
+// do()'s self-ensemble for the image pair already in io_x / io_x2; leaves the float64 mean in ens_out (enqueued, not synchronised)
+static int ensemble_on_device(dcscn_ctx* h, int height, int width, int n) {
+    const int s = h->cfg.scale;
     const size_t lr = (size_t)height * width, hr = lr * s * s;
     const int na = std::min(n, 4), nb = n - na;               // types 0-3 keep [h, w]; 4-7 are [w, h]
-    // device buffers: the image pair, its n flipped copies, their outputs, the float64 mean
-    int rc = ensure_io(h, lr, hr);
-    if (!rc) rc = grow(h, &h->ens_x, &h->ens_x_cap, n * lr, h->stream);
+    int rc = grow(h, &h->ens_x, &h->ens_x_cap, n * lr, h->stream);
     if (!rc) rc = grow(h, &h->ens_x2, &h->ens_x2_cap, n * hr, h->stream);
     if (!rc) rc = grow(h, &h->ens_y, &h->ens_y_cap, n * hr, h->stream);
     if (!rc) rc = grow(h, &h->ens_out, &h->ens_out_cap, 2 * hr, h->stream);     // doubles
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpy(h->io_x, x, lr * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->io_x2, x2, hr * sizeof(float), hipMemcpyHostToDevice));
     // util.flip(image, i) for i < n (DCSCN.py:562-564), on the device
     HIP_TRY(h, ensemble_gather_launch(h->io_x, h->ens_x, height, width, n, h->stream));
     HIP_TRY(h, ensemble_gather_launch(h->io_x2, h->ens_x2, height * s, width * s, n, h->stream));
@@ -1605,8 +1599,164 @@ int dcscn_forward_ensemble(dcscn_handle h, const float* x, const float* x2, doub
     if (rc) return rc;
     // output = zeros(float64); output += flip(y_i, invert=True) for i ascending; output /= n  (DCSCN.py:560-573)
     HIP_TRY(h, ensemble_reduce_launch(h->ens_y, reinterpret_cast<double*>(h->ens_out), height * s, width * s, n, h->stream));
+    return DCSCN_OK;
+}
+
+int dcscn_forward_ensemble(dcscn_handle h, const float* x, const float* x2, double* y, int height, int width, int n_ensemble) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_forward_ensemble before dcscn_finalize");
+    if (!x || !x2 || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
+    if (n_ensemble < 1 || n_ensemble > 8) return fail(h, DCSCN_ERR_INVALID_ARG, "n_ensemble %d outside [1, 8]", n_ensemble);
+    if (height <= 0 || width <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape h=%d w=%d", height, width);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int s = h->cfg.scale;
+    const size_t lr = (size_t)height * width, hr = lr * s * s;
+    int rc = ensure_io(h, lr, hr);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(h->io_x, x, lr * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->io_x2, x2, hr * sizeof(float), hipMemcpyHostToDevice));
+    rc = ensemble_on_device(h, height, width, n_ensemble);
+    if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(y, h->ens_out, hr * sizeof(double), hipMemcpyDeviceToHost));
+    return DCSCN_OK;
+}
+
+// ---- colour conversions and the RGB pipelines of evaluate.py / sr.py (color.hip) ---------------------------------
+
+static int color_args(dcscn_handle h, const void* a, const void* b, int64_t n, const char* what) {
+    if (!a || !b) return fail(h, DCSCN_ERR_INVALID_ARG, "%s: null pointer", what);
+    if (n < 0) return fail(h, DCSCN_ERR_INVALID_ARG, "%s: negative pixel count", what);
+    return DCSCN_OK;
+}
+
+int dcscn_convert_rgb_to_y(dcscn_handle h, const uint8_t* rgb, double* y, int64_t n_pixels) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    int rc = color_args(h, rgb, y, n_pixels, "dcscn_convert_rgb_to_y");
+    if (rc || n_pixels == 0) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = grow(h, &h->col_rgb, &h->col_rgb_cap, (size_t)(3 * n_pixels + 3) / 4, h->stream);
+    if (!rc) rc = grow(h, &h->col_d, &h->col_d_cap, (size_t)2 * n_pixels, h->stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(h->col_rgb, rgb, (size_t)3 * n_pixels, hipMemcpyHostToDevice));
+    HIP_TRY(h, rgb_to_y_launch(reinterpret_cast<const uint8_t*>(h->col_rgb), reinterpret_cast<double*>(h->col_d), nullptr, n_pixels, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(y, h->col_d, (size_t)n_pixels * sizeof(double), hipMemcpyDeviceToHost));
+    return DCSCN_OK;
+}
+
+int dcscn_convert_rgb_to_ycbcr(dcscn_handle h, const uint8_t* rgb, double* ycbcr, int64_t n_pixels) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    int rc = color_args(h, rgb, ycbcr, n_pixels, "dcscn_convert_rgb_to_ycbcr");
+    if (rc || n_pixels == 0) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = grow(h, &h->col_rgb, &h->col_rgb_cap, (size_t)(3 * n_pixels + 3) / 4, h->stream);
+    if (!rc) rc = grow(h, &h->col_d, &h->col_d_cap, (size_t)6 * n_pixels, h->stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(h->col_rgb, rgb, (size_t)3 * n_pixels, hipMemcpyHostToDevice));
+    HIP_TRY(h, rgb_to_ycbcr_launch(reinterpret_cast<const uint8_t*>(h->col_rgb), reinterpret_cast<double*>(h->col_d), n_pixels, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(ycbcr, h->col_d, (size_t)3 * n_pixels * sizeof(double), hipMemcpyDeviceToHost));
+    return DCSCN_OK;
+}
+
+int dcscn_convert_y_and_cbcr_to_rgb(dcscn_handle h, const double* y, const double* cbcr, double* rgb, int64_t n_pixels) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    int rc = color_args(h, y, cbcr, n_pixels, "dcscn_convert_y_and_cbcr_to_rgb");
+    if (!rc && !rgb) rc = fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_convert_y_and_cbcr_to_rgb: null pointer");
+    if (rc || n_pixels == 0) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = grow(h, &h->col_d, &h->col_d_cap, (size_t)6 * n_pixels, h->stream);            // y | cbcr
+    if (!rc) rc = grow(h, &h->col_d2, &h->col_d2_cap, (size_t)6 * n_pixels, h->stream);
+    if (rc) return rc;
+    double* dy = reinterpret_cast<double*>(h->col_d);
+    double* dc = dy + n_pixels;
+    HIP_TRY(h, hipMemcpy(dy, y, (size_t)n_pixels * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(dc, cbcr, (size_t)2 * n_pixels * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, y_cbcr_to_rgb_launch(dy, nullptr, dc, nullptr, reinterpret_cast<double*>(h->col_d2), n_pixels, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(rgb, h->col_d2, (size_t)3 * n_pixels * sizeof(double), hipMemcpyDeviceToHost));
+    return DCSCN_OK;
+}
+
+// Y image already on the device in col_y32 [H, W] (float32 of the float64 luma) -> LR, x2, y on the device.
+// Leaves the result as float32 in io_y (n_ensemble == 1) or as float64 in ens_out (n_ensemble > 1); enqueued only.
+static int sr_from_lr_on_device(dcscn_ctx* h, int lh, int lw, int n_ensemble) {
+    const int s = h->cfg.scale;
+    int rc = resize_device(h, h->io_x, h->io_x2, 1, lh, lw, lh * s, lw * s, h->stream);                 // DCSCN.py:552-554 / 683
+    if (rc) return rc;
+    if (n_ensemble > 1) return ensemble_on_device(h, lh, lw, n_ensemble);
+    return run_forward(h, h->io_x, h->io_x2, h->io_y, 1, lh, lw, h->stream);
+}
+
+static int download_sr(dcscn_ctx* h, size_t hr, int n_ensemble, double* y) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (n_ensemble > 1) {
+        HIP_TRY(h, hipMemcpy(y, h->ens_out, hr * sizeof(double), hipMemcpyDeviceToHost));
+    } else {                                   // sess.run returns float32 (DCSCN.py:575-578): widened exactly
+        std::vector<float> tmp(hr);
+        HIP_TRY(h, hipMemcpy(tmp.data(), h->io_y, hr * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < hr; ++i) y[i] = (double)tmp[i];
+    }
+    return DCSCN_OK;
+}
+
+int dcscn_evaluate_rgb(dcscn_handle h, const uint8_t* rgb, int height, int width, int n_ensemble, double* true_y, float* lr, double* y) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_evaluate_rgb before dcscn_finalize");
+    if (!rgb || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_evaluate_rgb: null pointer");
+    if (n_ensemble < 1 || n_ensemble > 8) return fail(h, DCSCN_ERR_INVALID_ARG, "n_ensemble %d outside [1, 8]", n_ensemble);
+    const int s = h->cfg.scale;
+    if (height <= 0 || width <= 0 || height % s || width % s)
+        return fail(h, DCSCN_ERR_INVALID_ARG, "image %dx%d is not aligned to the scale %d (set_image_alignment, utilty.py:196-208)", height, width, s);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int lh = height / s, lw = width / s;
+    const size_t hr = (size_t)height * width, lrn = (size_t)lh * lw;
+    int rc = ensure_io(h, lrn, hr);
+    if (!rc) rc = grow(h, &h->col_rgb, &h->col_rgb_cap, (3 * hr + 3) / 4, h->stream);
+    if (!rc) rc = grow(h, &h->col_d, &h->col_d_cap, 2 * hr, h->stream);
+    if (!rc) rc = grow(h, &h->col_y32, &h->col_y32_cap, hr, h->stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(h->col_rgb, rgb, 3 * hr, hipMemcpyHostToDevice));
+    // convert_rgb_to_y in float64 (utilty.py:146-147); the LR image is Pillow's BICUBIC on the mode-'F' (float32) copy of it
+    HIP_TRY(h, rgb_to_y_launch(reinterpret_cast<const uint8_t*>(h->col_rgb), reinterpret_cast<double*>(h->col_d), h->col_y32, (long long)hr, h->stream));
+    rc = resize_device(h, h->col_y32, h->io_x, 1, height, width, lh, lw, h->stream);                    // loader.py:64-65
+    if (!rc) rc = sr_from_lr_on_device(h, lh, lw, n_ensemble);
+    if (!rc) rc = download_sr(h, hr, n_ensemble, y);
+    if (rc) return rc;
+    if (true_y) HIP_TRY(h, hipMemcpy(true_y, h->col_d, hr * sizeof(double), hipMemcpyDeviceToHost));
+    if (lr) HIP_TRY(h, hipMemcpy(lr, h->io_x, lrn * sizeof(float), hipMemcpyDeviceToHost));
+    return DCSCN_OK;
+}
+
+int dcscn_sr_rgb(dcscn_handle h, const uint8_t* rgb, const uint8_t* rgb_upscaled, int height, int width, int n_ensemble, double* y, double* rgb_out) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_sr_rgb before dcscn_finalize");
+    if (!rgb || !rgb_upscaled || !rgb_out) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_sr_rgb: null pointer");
+    if (n_ensemble < 1 || n_ensemble > 8) return fail(h, DCSCN_ERR_INVALID_ARG, "n_ensemble %d outside [1, 8]", n_ensemble);
+    if (height <= 0 || width <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "bad shape h=%d w=%d", height, width);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int s = h->cfg.scale;
+    const size_t lrn = (size_t)height * width, hr = lrn * s * s;
+    int rc = ensure_io(h, lrn, hr);
+    if (!rc) rc = grow(h, &h->col_rgb, &h->col_rgb_cap, (3 * hr + 3) / 4 + (3 * lrn + 3) / 4 + 4, h->stream);
+    if (!rc) rc = grow(h, &h->col_d2, &h->col_d2_cap, 6 * hr, h->stream);
+    if (rc) return rc;
+    uint8_t* d_up = reinterpret_cast<uint8_t*>(h->col_rgb);
+    uint8_t* d_lr = d_up + ((3 * hr + 15) & ~(size_t)15);
+    HIP_TRY(h, hipMemcpy(d_lr, rgb, 3 * lrn, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(d_up, rgb_upscaled, 3 * hr, hipMemcpyHostToDevice));
+    // input_y_image = convert_rgb_to_y(org_image); do(input_y_image): x = float32(Y) (DCSCN.py:597-601)
+    HIP_TRY(h, rgb_to_y_launch(d_lr, nullptr, h->io_x, (long long)lrn, h->stream));
+    rc = sr_from_lr_on_device(h, height, width, n_ensemble);
+    if (rc) return rc;
+    // convert_y_and_cbcr_to_rgb(output_y, convert_rgb_to_ycbcr(bicubic RGB)[:, :, 1:3]) (DCSCN.py:603-605)
+    HIP_TRY(h, y_cbcr_to_rgb_launch(n_ensemble > 1 ? reinterpret_cast<const double*>(h->ens_out) : nullptr, n_ensemble > 1 ? nullptr : h->io_y,
+                                    nullptr, d_up, reinterpret_cast<double*>(h->col_d2), (long long)hr, h->stream));
+    if (y) rc = download_sr(h, hr, n_ensemble, y);
+    else HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(rgb_out, h->col_d2, 3 * hr * sizeof(double), hipMemcpyDeviceToHost));
     return DCSCN_OK;
 }
 
@@ -1661,7 +1811,8 @@ int dcscn_destroy(dcscn_handle h) {
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (void* p : h->device_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
-    for (float* p : {h->tile_x, h->tile_x2, h->tile_y, h->rs_tmp, h->rs_in, h->rs_out, h->ens_x, h->ens_x2, h->ens_y, h->ens_out})
+    for (float* p : {h->tile_x, h->tile_x2, h->tile_y, h->rs_tmp, h->rs_in, h->rs_out, h->ens_x, h->ens_x2, h->ens_y, h->ens_out, h->col_rgb, h->col_d,
+                     h->col_d2, h->col_y32})
         if (p) (void)hipFree(p);
     if (h->io_x) (void)hipFree(h->io_x);
     if (h->io_x2) (void)hipFree(h->io_x2);

@@ -87,6 +87,12 @@ int conv_max_fused_dw_nt();
 hipError_t ensemble_gather_launch(const float* in, float* out, int h, int w, int n, hipStream_t stream);
 hipError_t ensemble_reduce_launch(const float* y, double* out, int h, int w, int n, hipStream_t stream);
 
+// colour conversions of helper/utilty.py:142-193 in float64 (color.hip); device pointers
+hipError_t rgb_to_y_launch(const uint8_t* rgb, double* y64, float* y32, long long n, hipStream_t stream);
+hipError_t rgb_to_ycbcr_launch(const uint8_t* rgb, double* out, long long n, hipStream_t stream);
+hipError_t y_cbcr_to_rgb_launch(const double* y64, const float* y32, const double* cbcr, const uint8_t* rgb8, double* out, long long n,
+                                hipStream_t stream);
+
 // Pillow-compatible bicubic resize of 1-channel float images (resample.hip)
 int resample_coeffs(int in_size, int out_size, std::vector<int>* bounds, std::vector<double>* kk);   // returns ksize
 hipError_t resample_h_launch(const float* in, float* out, const int* bounds, const double* kk, int ksize,

@@ -26,7 +26,8 @@ EXPORTED_SYMBOLS = (
     "dcscn_layer_info_get", "dcscn_num_ops", "dcscn_op_info_get", "dcscn_set_option", "dcscn_forward",
     "dcscn_forward_device", "dcscn_forward_ensemble", "dcscn_get_profile", "dcscn_workspace_bytes",
     "dcscn_last_error", "dcscn_destroy", "dcscn_resize_bicubic", "dcscn_resize_bicubic_device", "dcscn_forward_lr",
-    "dcscn_resample_table", "dcscn_get_stream", "dcscn_synchronize",
+    "dcscn_resample_table", "dcscn_get_stream", "dcscn_synchronize", "dcscn_convert_rgb_to_y", "dcscn_convert_rgb_to_ycbcr",
+    "dcscn_convert_y_and_cbcr_to_rgb", "dcscn_evaluate_rgb", "dcscn_sr_rgb",
 )
 
 
@@ -140,6 +141,12 @@ def load_library():
     lib.dcscn_get_profile.argtypes = [vp, dp, c.c_int]
     lib.dcscn_workspace_bytes.argtypes = [vp]
     lib.dcscn_get_stream.argtypes = [vp, c.POINTER(vp)]
+    u8p = c.POINTER(c.c_uint8)
+    lib.dcscn_convert_rgb_to_y.argtypes = [vp, u8p, dp, c.c_int64]
+    lib.dcscn_convert_rgb_to_ycbcr.argtypes = [vp, u8p, dp, c.c_int64]
+    lib.dcscn_convert_y_and_cbcr_to_rgb.argtypes = [vp, dp, dp, dp, c.c_int64]
+    lib.dcscn_evaluate_rgb.argtypes = [vp, u8p, c.c_int, c.c_int, c.c_int, dp, fp, dp]
+    lib.dcscn_sr_rgb.argtypes = [vp, u8p, u8p, c.c_int, c.c_int, c.c_int, dp, dp]
     lib.dcscn_synchronize.argtypes = [vp]
     lib.dcscn_workspace_bytes.restype = c.c_int64
     lib.dcscn_last_error.argtypes = [vp]
@@ -373,6 +380,70 @@ class Engine:
         self._check(self._lib.dcscn_forward_device(self._h, ctypes.c_void_p(x_ptr), ctypes.c_void_p(x2_ptr),
                                                    ctypes.c_void_p(y_ptr), n, h, w,
                                                    ctypes.c_void_p(stream) if stream else None))
+
+    # ---- colour path (helper/utilty.py:142-193 and the RGB pipelines of evaluate.py / sr.py on the device) ----
+    @staticmethod
+    def _rgb8(image):
+        a = np.ascontiguousarray(image)
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+            raise EngineError(1, "expected a uint8 RGB image [h, w, 3]")
+        return a
+
+    def convert_rgb_to_y(self, image):
+        a = self._rgb8(image)
+        out = np.empty(a.shape[:2] + (1,), np.float64)
+        self._check(self._lib.dcscn_convert_rgb_to_y(self._h, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                                     out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), a.shape[0] * a.shape[1]))
+        return out
+
+    def convert_rgb_to_ycbcr(self, image):
+        a = self._rgb8(image)
+        out = np.empty(a.shape, np.float64)
+        self._check(self._lib.dcscn_convert_rgb_to_ycbcr(self._h, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                                         out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), a.shape[0] * a.shape[1]))
+        return out
+
+    def convert_y_and_cbcr_to_rgb(self, y_image, cbcr_image):
+        dp = ctypes.POINTER(ctypes.c_double)
+        y = np.ascontiguousarray(np.asarray(y_image, np.float64).reshape(y_image.shape[0], y_image.shape[1], -1)[:, :, 0])
+        cbcr = np.ascontiguousarray(np.asarray(cbcr_image, np.float64)[:, :, 0:2])
+        out = np.empty(y.shape + (3,), np.float64)
+        self._check(self._lib.dcscn_convert_y_and_cbcr_to_rgb(self._h, y.ctypes.data_as(dp), cbcr.ctypes.data_as(dp), out.ctypes.data_as(dp), y.size))
+        return out
+
+    def evaluate_rgb(self, true_image, n_ensemble=1, want_inputs=False):
+        """do_for_evaluate's pipeline for an aligned uint8 RGB image: returns (true_y float64 [H, W, 1], y [H, W, 1]
+        -- float32 for n_ensemble <= 1 like sess.run, float64 otherwise like do()'s mean) and, with want_inputs, the LR input."""
+        a = self._rgb8(true_image)
+        hh, ww = a.shape[:2]
+        s = self.scale
+        true_y = np.empty((hh, ww, 1), np.float64)
+        y = np.empty((hh, ww, 1), np.float64)
+        lr = np.empty((hh // s, ww // s, 1), np.float32) if want_inputs else None
+        self._check(self._lib.dcscn_evaluate_rgb(self._h, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), hh, ww, max(1, int(n_ensemble)),
+                                                 true_y.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                 lr.ctypes.data_as(ctypes.POINTER(ctypes.c_float)) if want_inputs else None,
+                                                 y.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        if n_ensemble <= 1:
+            y = y.astype(np.float32)
+        return (true_y, y, lr) if want_inputs else (true_y, y)
+
+    def sr_rgb(self, image, upscaled_image, n_ensemble=1):
+        """do_for_file's colour branch: (super-resolved Y [s*h, s*w, 1], RGB float64 [s*h, s*w, 3])."""
+        a, b = self._rgb8(image), self._rgb8(upscaled_image)
+        h, w = a.shape[:2]
+        s = self.scale
+        if b.shape[:2] != (h * s, w * s):
+            raise EngineError(1, "the upscaled image must be %d times the input" % s)
+        y = np.empty((h * s, w * s, 1), np.float64)
+        rgb = np.empty((h * s, w * s, 3), np.float64)
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        dp = ctypes.POINTER(ctypes.c_double)
+        self._check(self._lib.dcscn_sr_rgb(self._h, a.ctypes.data_as(u8), b.ctypes.data_as(u8), h, w, max(1, int(n_ensemble)),
+                                           y.ctypes.data_as(dp), rgb.ctypes.data_as(dp)))
+        if n_ensemble <= 1:
+            y = y.astype(np.float32)
+        return y, rgb
 
     def forward_ensemble(self, x, x2, n_ensemble):
         """One image [h, w(,1)] + bicubic [s*h, s*w(,1)] -> float64 [s*h, s*w, 1] (do(), DCSCN.py:559-573)."""

@@ -309,16 +309,28 @@ class SuperResolution:
             input_y_image = util.convert_rgb_to_y(org_image)
             scaled_image = util.resize_image_by_pil(input_y_image, self.scale, resampling_method=self.resampling_method)
             util.save_image(output_folder + filename + "_bicubic_y" + extension, scaled_image)
-            output_y_image = self.do(input_y_image)
-            util.save_image(output_folder + filename + "_result_y" + extension, output_y_image)
-            scaled_ycbcr_image = util.convert_rgb_to_ycbcr(
-                util.resize_image_by_pil(org_image, self.scale, self.resampling_method))
-            image = util.convert_y_and_cbcr_to_rgb(output_y_image, scaled_ycbcr_image[:, :, 1:3])
+            if self._device_colour_path(org_image):
+                # Y, x2, the forward pass and the YCbCr -> RGB recombination in one device pipeline (dcscn_sr_rgb)
+                scaled_rgb = util.resize_image_by_pil(org_image, self.scale, self.resampling_method)
+                output_y_image, image = self._ready_engine().sr_rgb(org_image, scaled_rgb, self.self_ensemble)
+                util.save_image(output_folder + filename + "_result_y" + extension, output_y_image)
+            else:
+                output_y_image = self.do(input_y_image)
+                util.save_image(output_folder + filename + "_result_y" + extension, output_y_image)
+                scaled_ycbcr_image = util.convert_rgb_to_ycbcr(
+                    util.resize_image_by_pil(org_image, self.scale, self.resampling_method))
+                image = util.convert_y_and_cbcr_to_rgb(output_y_image, scaled_ycbcr_image[:, :, 1:3])
         else:
             scaled_image = util.resize_image_by_pil(org_image, self.scale, resampling_method=self.resampling_method)
             util.save_image(output_folder + filename + "_bicubic_y" + extension, scaled_image)
             image = self.do(org_image)
         util.save_image(output_folder + filename + "_result" + extension, image)
+
+    def _device_colour_path(self, image):
+        """uint8 RGB through the device colour / bicubic kernels: they reproduce the float64 numpy colour math and
+        Pillow's mode-'F' BICUBIC only (other resampling methods, other value ranges stay on the host path)."""
+        return (self.resampling_method == BICUBIC_METHOD_STRING and self.max_value == 255.0 and self.channels == 1
+                and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3)
 
     def _evaluation_inputs(self, file_path):
         """(true image aligned, true Y or grey, LR input, bicubic of LR) -- DCSCN.py:674-683."""
@@ -337,10 +349,15 @@ class SuperResolution:
 
     def do_for_evaluate(self, file_path, print_console=False):
         """(psnr, ssim) of one file (DCSCN.py:672-703)."""
-        true_image, true_y, input_image, bicubic = self._evaluation_inputs(file_path)
-        if true_y is None:
-            return None, None
-        output = self.do(input_image, bicubic)
+        true_image = util.set_image_alignment(util.load_image(file_path, print_console=False), self.scale)
+        if self._device_colour_path(true_image):
+            # one upload: Y conversion, both bicubic resizes, the (ensemble of) forward pass on the device (dcscn_evaluate_rgb)
+            true_y, output = self._ready_engine().evaluate_rgb(true_image, self.self_ensemble)
+        else:
+            true_image, true_y, input_image, bicubic = self._evaluation_inputs(file_path)
+            if true_y is None:
+                return None, None
+            output = self.do(input_image, bicubic)
         psnr, ssim = util.compute_psnr_and_ssim(true_y, output, border_size=self.psnr_calc_border_size)
         if print_console:
             print("[%s] PSNR:%f, SSIM:%f" % (file_path, psnr, ssim))

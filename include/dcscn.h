@@ -205,6 +205,31 @@ int dcscn_synchronize(dcscn_handle h);
 int dcscn_forward_ensemble(dcscn_handle h, const float* x, const float* x2, double* y,
                            int height, int width, int n_ensemble);
 
+/* Colour conversions of helper/utilty.py:142-193 on the device, float64 like the reference's numpy (host buffers,
+ * synchronous; usable before dcscn_finalize).  rgb: uint8 [n_pixels, 3] interleaved.
+ *   dcscn_convert_rgb_to_y            utilty.py:142-149   y     float64 [n_pixels]     = [65.738 129.057 25.064]/256 . rgb + 16
+ *   dcscn_convert_rgb_to_ycbcr        utilty.py:152-165   ycbcr float64 [n_pixels, 3]
+ *   dcscn_convert_y_and_cbcr_to_rgb   utilty.py:168-193   y float64 [n_pixels], cbcr float64 [n_pixels, 2] -> rgb float64 [n_pixels, 3] */
+int dcscn_convert_rgb_to_y(dcscn_handle h, const uint8_t* rgb, double* y, int64_t n_pixels);
+int dcscn_convert_rgb_to_ycbcr(dcscn_handle h, const uint8_t* rgb, double* ycbcr, int64_t n_pixels);
+int dcscn_convert_y_and_cbcr_to_rgb(dcscn_handle h, const double* y, const double* cbcr, double* rgb, int64_t n_pixels);
+
+/* do_for_evaluate's image pipeline (DCSCN.py:672-703, loader.py:42-67) with ONE upload: the aligned true image
+ * (uint8 RGB [height, width, 3], both multiples of the scale) -> Y in float64 (convert_rgb_to_y) -> LR = Pillow BICUBIC
+ * of the mode-'F' Y at 1/scale -> x2 = BICUBIC of LR at scale -> do() with self_ensemble = n_ensemble.
+ * Outputs (host): y float64 [height, width] (n_ensemble == 1: the float32 network output, widened), and optionally
+ * true_y float64 [height, width] (what the PSNR is measured against) and lr float32 [height/s, width/s]. */
+int dcscn_evaluate_rgb(dcscn_handle h, const uint8_t* rgb, int height, int width, int n_ensemble,
+                       double* true_y, float* lr, double* y);
+
+/* do_for_file's colour pipeline (sr.py; DCSCN.py:588-614): rgb uint8 [height, width, 3] is the input image,
+ * rgb_upscaled uint8 [s*height, s*width, 3] its Pillow-upscaled copy (the reference builds it on the host for the
+ * "_bicubic" output anyway; Pillow's uint8 RGB resize is integer arithmetic and stays there).  Device: Y of the input
+ * -> x, x2 = BICUBIC(x), do() -> y; CbCr of rgb_upscaled; rgb_out = convert_y_and_cbcr_to_rgb(y, cbcr), float64
+ * [s*height, s*width, 3].  y (optional) receives the super-resolved luma, float64. */
+int dcscn_sr_rgb(dcscn_handle h, const uint8_t* rgb, const uint8_t* rgb_upscaled, int height, int width, int n_ensemble,
+                 double* y, double* rgb_out);
+
 /* Per-launch (dcscn_op_info order) device milliseconds, summed over sub-batches and averaged over
  * the forwards run with the profile option on since the previous call (which this call resets);
  * `ms` receives min(capacity, num_ops) entries.  Synchronises the device. */

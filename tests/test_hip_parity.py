@@ -310,29 +310,78 @@ def test_spatial_tiling_window_too_small(oracle):
             eng.forward(x, x2)
 
 
+class _Hip:
+    """The few HIP runtime calls the device-pointer test needs, through ctypes (the runtime the library itself loaded)."""
+
+    def __init__(self):
+        import ctypes
+        self.c = ctypes
+        self.lib = ctypes.CDLL("libamdhip64.so")
+        self.lib.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        self.lib.hipFree.argtypes = [ctypes.c_void_p]
+        self.lib.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self.lib.hipStreamCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.lib.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+        self.ptrs, self.streams = [], []
+
+    def _ok(self, rc):
+        assert rc == 0, "HIP error %d" % rc
+
+    def upload(self, a):
+        p = self.c.c_void_p()
+        self._ok(self.lib.hipMalloc(self.c.byref(p), a.nbytes))
+        self._ok(self.lib.hipMemcpy(p, a.ctypes.data_as(self.c.c_void_p), a.nbytes, 1))      # hipMemcpyHostToDevice
+        self.ptrs.append(p)
+        return p.value
+
+    def alloc(self, nbytes):
+        p = self.c.c_void_p()
+        self._ok(self.lib.hipMalloc(self.c.byref(p), nbytes))
+        self.ptrs.append(p)
+        return p.value
+
+    def download(self, ptr, shape):
+        out = np.empty(shape, np.float32)
+        self._ok(self.lib.hipMemcpy(out.ctypes.data_as(self.c.c_void_p), self.c.c_void_p(ptr), out.nbytes, 2))   # DeviceToHost
+        return out
+
+    def stream(self):
+        s = self.c.c_void_p()
+        self._ok(self.lib.hipStreamCreate(self.c.byref(s)))
+        self.streams.append(s)
+        return s.value
+
+    def close(self):
+        for s in self.streams:
+            self.lib.hipStreamDestroy(s)
+        for p in self.ptrs:
+            self.lib.hipFree(p)
+
+
 def test_forward_device_alternating_shapes_and_streams(oracle):
     """two shapes alternate through dcscn_forward_device on user streams with no sync in between.  The
     second shape fits the arena of the first, so the re-carve neither frees nor synchronises; the library must
     order its clear (and the forward) behind the previous call -- every output must still match a fresh run."""
-    torch = pytest.importorskip("torch")
     cfg = oracle.make_config(**CONFIGS["L7_F32to8_x2"])
     weights = oracle.synthetic_weights(cfg, seed=3)
     shapes = [(6, 48, 40), (3, 24, 56)]
     data = [synthetic_batch(n, h, w, 2, seed=20 + i) for i, (n, h, w) in enumerate(shapes)]
-    with _engine(cfg, weights) as eng:
-        expect = [eng.forward(x, x2) for x, x2 in data]
-        dev = [(torch.from_numpy(x).cuda(), torch.from_numpy(x2).cuda()) for x, x2 in data]
-        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-        outs = []
-        torch.cuda.synchronize()
-        for it in range(8):
-            k = it & 1
-            xd, x2d = dev[k]
-            y = torch.empty_like(x2d)
-            n, h, w = shapes[k]
-            eng.forward_device(xd.data_ptr(), x2d.data_ptr(), y.data_ptr(), n, h, w, stream=streams[(it // 2) & 1].cuda_stream)
-            outs.append((k, y))
-        eng.synchronize()
-        for k, y in outs:
-            assert np.array_equal(y.cpu().numpy(), expect[k]), "output of an un-synchronised call differs"
-        assert eng.stream() != 0
+    hip = _Hip()
+    try:
+        with _engine(cfg, weights) as eng:
+            expect = [eng.forward(x, x2) for x, x2 in data]
+            dev = [(hip.upload(x), hip.upload(x2)) for x, x2 in data]
+            streams = [hip.stream(), hip.stream()]
+            outs = []
+            for it in range(8):
+                k = it & 1
+                n, h, w = shapes[k]
+                y = hip.alloc(expect[k].nbytes)
+                eng.forward_device(dev[k][0], dev[k][1], y, n, h, w, stream=streams[(it // 2) & 1])
+                outs.append((k, y))
+            eng.synchronize()
+            for k, y in outs:
+                assert np.array_equal(hip.download(y, expect[k].shape), expect[k]), "output of an un-synchronised call differs"
+            assert eng.stream() != 0
+    finally:
+        hip.close()
