@@ -210,3 +210,151 @@ def load_checkpoint(prefix, include_optimizer_slots=False):
 def is_optimizer_slot(name):
     leaf = name.rsplit("/", 1)[-1]
     return leaf in ("Adam", "Adam_1") or name in ("beta1_power", "beta2_power")
+
+
+# ------------------------------------------------------------------------------------------------
+# writer: tf.train.Saver.save without TensorFlow (helper/tf_graph.py:282-296 save_model)
+# ------------------------------------------------------------------------------------------------
+# Produces the same two files the reference's checkpoints consist of; written the way TensorFlow's BundleWriter and
+# its LevelDB-style table builder write them (sorted keys, prefix compression with a restart point every 16 entries,
+# one uncompressed data block per 256 KB, shortest-successor index keys, masked CRC32C of every block and of every
+# tensor), so a file written here from the tensors of a reference checkpoint is byte-identical to the original
+# (tests/test_checkpoint_writer.py) and TensorFlow's own reader accepts it.
+
+_CRC_TABLE = None
+
+
+def _crc32c(data, crc=0):
+    """CRC-32C (Castagnoli), table driven; numpy-free so that it also runs on bytes objects of any size."""
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        table = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            table.append(c)
+        _CRC_TABLE = table
+    table = _CRC_TABLE
+    crc ^= 0xFFFFFFFF
+    for b in data:
+        crc = table[(crc ^ b) & 0xFF] ^ (crc >> 8)
+    return crc ^ 0xFFFFFFFF
+
+
+def _masked_crc(data):
+    crc = _crc32c(data)
+    return (((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _put_varint(value):
+    out = bytearray()
+    while True:
+        b = value & 0x7F
+        value >>= 7
+        if value:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _build_block(items, restart_interval):
+    """LevelDB block: prefix-compressed entries + restart array."""
+    out = bytearray()
+    restarts = []
+    last = b""
+    for i, (key, value) in enumerate(items):
+        shared = 0
+        if i % restart_interval == 0:
+            restarts.append(len(out))
+        else:
+            n = min(len(last), len(key))
+            while shared < n and last[shared] == key[shared]:
+                shared += 1
+        out += _put_varint(shared) + _put_varint(len(key) - shared) + _put_varint(len(value)) + key[shared:] + value
+        last = key
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        out += struct.pack("<I", r)
+    out += struct.pack("<I", len(restarts))
+    return bytes(out)
+
+
+def _short_successor(key):
+    for i, b in enumerate(key):
+        if b != 0xFF:
+            return key[:i] + bytes([b + 1])
+    return key
+
+
+def _shortest_separator(start, limit):
+    n = min(len(start), len(limit))
+    i = 0
+    while i < n and start[i] == limit[i]:
+        i += 1
+    if i < n and start[i] < 0xFF and start[i] + 1 < limit[i]:
+        return start[:i] + bytes([start[i] + 1])
+    return start
+
+
+def _entry_proto(shape, offset, size, crc):
+    dims = b"".join(b"\x12" + _put_varint(len(d)) + d for d in (b"\x08" + _put_varint(int(s)) for s in shape))
+    out = b"\x08\x01" + b"\x12" + _put_varint(len(dims)) + dims          # dtype = DT_FLOAT, shape
+    if offset:
+        out += b"\x20" + _put_varint(offset)
+    out += b"\x28" + _put_varint(size) + b"\x35" + struct.pack("<I", crc)
+    return out
+
+
+def save_checkpoint(prefix, tensors, block_size=256 << 10):
+    """Write ``<prefix>.index`` and ``<prefix>.data-00000-of-00001`` holding ``{name: float32 ndarray}``.
+
+    Variables are stored in sorted-name order, back to back (TensorFlow's BundleWriter layout).  Also refreshes the
+    ``checkpoint`` state file next to it the way tf.train.Saver does (model_checkpoint_path points at the new prefix)."""
+    directory = os.path.dirname(os.path.abspath(prefix))
+    os.makedirs(directory, exist_ok=True)
+    names = sorted(tensors, key=lambda s: s.encode("utf-8"))
+    data = bytearray()
+    items = [(b"", b"\x08\x01\x1a\x02\x08\x01")]                          # BundleHeaderProto: num_shards 1, version.producer 1
+    for name in names:
+        a = np.asarray(tensors[name], dtype="<f4")                       # (ascontiguousarray would turn a scalar into shape (1,))
+        raw = a.tobytes(order="C")
+        items.append((name.encode("utf-8"), _entry_proto(a.shape, len(data), len(raw), _masked_crc(raw))))
+        data += raw
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(bytes(data))
+
+    out = bytearray()
+    index_items = []
+
+    def emit(block_items, next_key):
+        block = _build_block(block_items, 16)
+        handle = _put_varint(len(out)) + _put_varint(len(block))
+        out.extend(block + b"\x00" + struct.pack("<I", _masked_crc(block + b"\x00")))
+        last = block_items[-1][0]
+        index_items.append((_shortest_separator(last, next_key) if next_key is not None else _short_successor(last), handle))
+
+    pending, pending_bytes = [], 0
+    for i, (key, value) in enumerate(items):
+        pending.append((key, value))
+        pending_bytes += len(key) + len(value) + 3
+        if pending_bytes >= block_size and i + 1 < len(items):
+            emit(pending, items[i + 1][0])
+            pending, pending_bytes = [], 0
+    emit(pending, None)
+    meta = _build_block([], 16)
+    meta_handle = _put_varint(len(out)) + _put_varint(len(meta))
+    out.extend(meta + b"\x00" + struct.pack("<I", _masked_crc(meta + b"\x00")))
+    index = _build_block(index_items, 1)
+    index_handle = _put_varint(len(out)) + _put_varint(len(index))
+    out.extend(index + b"\x00" + struct.pack("<I", _masked_crc(index + b"\x00")))
+    footer = meta_handle + index_handle
+    out.extend(footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", _TABLE_MAGIC))
+    with open(prefix + ".index", "wb") as f:
+        f.write(bytes(out))
+    base = os.path.basename(prefix)
+    with open(os.path.join(directory, "checkpoint"), "w") as f:
+        f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
+    return prefix

@@ -1288,8 +1288,6 @@ int dcscn_create(const dcscn_config* cfg, int device, dcscn_handle* out) {
     if (c.cnn_size != 1 && c.cnn_size != 3 && c.cnn_size != 5 && c.cnn_size != 7)
         return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "cnn_size %d (supported: 1, 3, 5, 7)", c.cnn_size);
     if (c.channels != 1) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "channels %d (the reference itself only supports 1)", c.channels);
-    if (!c.pixel_shuffler && c.depthwise_separable)
-        return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "transposed-conv upsampler together with depthwise_separable is not implemented");
     if (c.batch_norm) return fail(nullptr, DCSCN_ERR_UNSUPPORTED, "batch_norm is not implemented");
     float dummy;
     if (kernel_act(c.activator, &dummy) < 0) return fail(nullptr, DCSCN_ERR_INVALID_ARG, "Not implemented activator:%d", c.activator);

@@ -20,7 +20,7 @@ import sys
 
 import numpy as np
 
-from . import ckpt, engine, imaging as util
+from . import ckpt, engine, frozen, imaging as util
 
 BICUBIC_METHOD_STRING = "bicubic"
 
@@ -227,6 +227,39 @@ class SuperResolution:
             logging.info("Model restored [ %s ]." % filename)
         else:
             print("Model restored [ %s ]." % filename)
+
+    def save_model(self, name="", trial=0, output_log=False):
+        """tf.train.Saver.save (tf_graph.py:282-296): the model's variables as a TF V2 checkpoint
+        (``<checkpoint_dir>/<name>[_<trial>].ckpt.{index,data-00000-of-00001}`` + the ``checkpoint`` state file), written
+        without TensorFlow (ckpt.save_checkpoint; byte-identical to what the reference's Saver writes for the same tensors)."""
+        if name == "" or name == "default":
+            name = self.name
+        if trial > 0:
+            filename = self.checkpoint_dir + "/" + name + "_" + str(trial) + ".ckpt"
+        else:
+            filename = self.checkpoint_dir + "/" + name + ".ckpt"
+        tensors = self._weights if self._weights is not None else self._pending_init
+        if tensors is None:
+            self.init_all_variables()
+            tensors = self._pending_init
+        ckpt.save_checkpoint(filename, tensors)
+        if output_log:
+            logging.info("Model saved [%s]." % filename)
+        else:
+            print("Model saved [%s]." % filename)
+
+    def load_graph(self, frozen_graph_filename="./model_to_freeze/frozen_model_optimized.pb"):
+        """--frozenInference (DCSCN.py:192-220): the weights come from the Const nodes of a frozen GraphDef (variables keep
+        their checkpoint names through freeze_graph / optimize_for_inference); the topology is the one the flags describe,
+        and a file that does not fit it is rejected by the engine (missing variable / shape mismatch)."""
+        if not os.path.isfile(frozen_graph_filename):
+            print("Error. [%s] is not exist!" % frozen_graph_filename)
+            sys.exit(-1)
+        tensors = frozen.read_frozen_graph(frozen_graph_filename)
+        if not any(k.endswith(("/conv_W", "/pointwise_W")) for k in tensors):
+            tensors = frozen.read_frozen_graph(frozen_graph_filename, prefix="prefix/")     # a re-exported import_graph_def copy
+        self.load_weights({k: v for k, v in tensors.items() if not ckpt.is_optimizer_slot(k)})
+        print("Frozen graph loaded [ %s ]." % frozen_graph_filename)
 
     def load_weights(self, tensors):
         """Upload ``{variable name: ndarray}``.  Checkpoints written by the reference's older graph

@@ -27,23 +27,24 @@ def main(not_parsed_args):
     if len(not_parsed_args) > 1:
         print("Unknown args:%s" % not_parsed_args)
         exit()
-    if FLAGS.frozenInference:
-        print("Error. --frozenInference needs TensorFlow frozen graphs, which this build does not read.")
-        exit(-1)
-
     group = shard.init_from_env()
     if group.world > 1:
         FLAGS.gpu_device_id = group.local_rank
 
     model = DCSCN.SuperResolution(FLAGS, model_name=FLAGS.model_name)
-    model.build_graph()
-    model.build_summary_saver()
+    if FLAGS.frozenInference:
+        model.load_graph(FLAGS.frozen_graph_path)             # evaluate.py:50-52 of the reference
+        model.build_summary_saver(with_saver=False)
+    else:
+        model.build_graph()
+        model.build_summary_saver()
     model.init_all_variables()
 
     test_list = ["set5", "set14", "bsd100"] if FLAGS.test_dataset == "all" else [FLAGS.test_dataset]
 
     for i in range(FLAGS.tests):
-        model.load_model(FLAGS.load_model_name, trial=i, output_log=True if FLAGS.tests > 1 else False)
+        if not FLAGS.frozenInference:
+            model.load_model(FLAGS.load_model_name, trial=i, output_log=True if FLAGS.tests > 1 else False)
 
         if FLAGS.compute_bicubic:
             for test_data in test_list:

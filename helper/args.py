@@ -86,9 +86,9 @@ _TABLE = [
     (_I, "save_images_num", 20, "unused"),
     (_B, "save_meta_data", False, "unused"),
     (_I, "gpu_device_id", 0, "HIP device the engine runs on"),
-    # ---- frozen graphs (args.py:97-98): no .pb ships with the reference; rejected at run time
-    (_B, "frozenInference", False, "not supported"),
-    (_S, "frozen_graph_path", "./model_to_freeze/frozen_model_optimized.pb", "not supported"),
+    # ---- frozen graphs (args.py:97-98): weights from the Const nodes of a frozen GraphDef (dcscn-super-resolution_amd/frozen.py)
+    (_B, "frozenInference", False, "Flag for whether the model to evaluate is frozen."),
+    (_S, "frozen_graph_path", "./model_to_freeze/frozen_model_optimized.pb", "the path to a frozen model if performing inference from it"),
 ]
 for _define, _name, _default, _help in _TABLE:
     _define(_name, _default, _help)

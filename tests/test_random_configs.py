@@ -31,8 +31,6 @@ def _draw(rng):
         depthwise_separable=ds,
     )
     flags["min_filters"] = min(flags["min_filters"], flags["filters"])
-    if ds and not flags["pixel_shuffler"]:
-        flags["pixel_shuffler"] = True            # the reference's transposed conv is never separable
     if flags["cnn_size"] == 7:
         flags["filters"] = min(flags["filters"], 66)
     h, w = int(rng.integers(1, 41)), int(rng.integers(1, 41))
