@@ -18,7 +18,7 @@ def _images():
     out = [util.load_image(os.path.join(GOLDEN, "set5", f), print_console=False) for f in g["files"][:3]]
     rng = np.random.default_rng(5)
     out.append(rng.integers(0, 256, (37, 53, 3), dtype=np.uint8))
-    out.append(np.stack(np.meshgrid(np.arange(256), np.arange(256)) + [np.full((256, 256), 77)], -1).astype(np.uint8))
+    out.append(np.stack(list(np.meshgrid(np.arange(256), np.arange(256))) + [np.full((256, 256), 77)], -1).astype(np.uint8))
     return [im for im in out if im.ndim == 3 and im.shape[2] == 3]
 
 
@@ -73,8 +73,8 @@ def test_sr_rgb_equals_do_for_file_colour_branch(tmp_path):
 
 
 def test_evaluate_rgb_rejects_unaligned_images(tmp_path):
-    from dcscn_amd.engine import EngineError
     g, m = _model(tmp_path, "L7_x2")
-    with pytest.raises(EngineError):
+    with pytest.raises(Exception) as e:
         m._ready_engine().evaluate_rgb(np.zeros((31, 40, 3), np.uint8))
+    assert type(e.value).__name__ == "EngineError" and e.value.status == 1
     m.close()
