@@ -160,6 +160,7 @@ struct dcscn_ctx {
     bool has_last = false;
     bool profile = false;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
+    bool nin = true;                         // wide 1x1 convs on the LDS-DMA staged GEMM (conv_nin); option "nin_gemm" 0 = conv_igemm
     bool fold_tail = true;                   // graph rewrite of the linear tail, see fold_linear_tail(); option "fold_linear_tail" 0 = layer by layer
     bool spatial_tiling = true;              // images larger than one pass are cut into haloed windows (run_tiled)
     std::vector<hipEvent_t> ev;              // event pool: 2 per launch
@@ -623,6 +624,13 @@ int op_tiles16(const Op& op) {
 // kernel).  A layer's 16-channel tiles are spread evenly over ceil(tiles / 3) channel groups (10 tiles = 3+3+2+2): a
 // group's cost is only partly its MFMA count (the input tile and its transform are per group), so a 1-tile group costs
 // ~70 % of a 3-tile one.  (op.vec4: the Winograd epilogue only has the 16-byte store form.)
+// 1x1 convs wide enough to be worth the LDS-DMA GEMM (conv_nin): plain conv + bias + activator into one or two NHWC
+// slices; everything with a fused depthwise stage, depth_to_space, a residual or scalar stores stays on conv_igemm.
+bool nin_eligible(const dcscn_ctx* h, const Op& op) {
+    return h->nin && op.kind == OP_CONV && op.ks == 1 && op.dwk == 0 && op.ps == 1 && !op.residual && op.vec4 && op.fold_s == 0 &&
+           op.tconv_s == 0 && op.cin_phys >= 32 && op.in_stride_override == 0;
+}
+
 bool wino_eligible(const dcscn_ctx* h, const Op& op) {
     const int tiles16 = op_tiles16(op);
     return h->winograd && op.kind == OP_CONV && op.vec4 && op.ks == 3 && op.dwk == 0 && op.cin_phys >= 32 &&
@@ -800,11 +808,57 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     int ctot = 0;
     for (const ColSeg& s : op.segs) ctot = std::max(ctot, s.dst + s.cout);
     const int tiles16 = (ctot + 15) / 16;
+    if (nin_eligible(h, op)) {
+        op.n_tiles = (tiles16 + kNinMaxNT - 1) / kNinMaxNT;                   // channel groups
+        const int nt = (tiles16 + op.n_tiles - 1) / op.n_tiles;
+        op.n_full = tiles16 - op.n_tiles * (nt - 1);
+        op.shape = ConvShape{1, 4, nt, kNinKC, 0, 1, 0};
+        op.ctot = op.n_tiles * nt * 16;
+        const int kc = kNinKC;
+        op.n_chunks = (op.cin_phys + kc - 1) / kc;
+        const int ns = conv_ns(nt);
+        const size_t chunk_floats = (size_t)kc * ns;
+        std::vector<float> pack((size_t)op.n_tiles * op.n_chunks * chunk_floats, 0.0f);
+        std::vector<float> bias(op.ctot, 0.0f), alpha(op.ctot, 0.0f);
+        auto padded = [&](int cc) {
+            const int t = cc / 16;
+            const int wide = op.n_full * nt;
+            const int g = t < wide ? t / nt : op.n_full + (t - wide) / (nt - 1);
+            const int tg = t < wide ? t % nt : (t - wide) % (nt - 1);
+            return (g * nt + tg) * 16 + cc % 16;
+        };
+        const int cin = (int)op.chan_map.size();
+        for (const ColSeg& sg : op.segs) {
+            const TensorSpec& tw = h->tensors[sg.w];                          // [1, 1, cin, cout]
+            const int wcols = (int)tw.shape.back();
+            for (int ci = 0; ci < cin; ++ci) {
+                const int kp = op.chan_map[ci];
+                const int chunk = kp / kc, c16 = kp % kc;
+                const int row = (c16 & 3) * 4 + (c16 >> 2);                   // k-step c16 & 3, MFMA k index c16 >> 2
+                const float dscale = sg.dw1 >= 0 ? h->tensors[sg.dw1].data[ci] : 1.0f;     // folded 1x1 depthwise
+                const float* wrow = &tw.data[(size_t)ci * wcols + sg.col0];
+                for (int co = 0; co < sg.cout; ++co) {
+                    const int pc = padded(sg.dst + co);
+                    const int grp = pc / (nt * 16), jn = pc % (nt * 16);
+                    pack[((size_t)grp * op.n_chunks + chunk) * chunk_floats + (size_t)row * ns + jn] = sg.dw1 >= 0 ? dscale * wrow[co] : wrow[co];
+                }
+            }
+            for (int co = 0; co < sg.cout; ++co) {
+                const int pc = padded(sg.dst + co);
+                if (sg.b >= 0) bias[pc] = h->tensors[sg.b].data[sg.col0 + co];
+                alpha[pc] = sg.alpha >= 0 ? h->tensors[sg.alpha].data[sg.col0 + co] : op.const_alpha;
+            }
+        }
+        int rcn = upload(h, pack.data(), pack.size() * sizeof(float), (void**)&op.d_w);
+        if (!rcn) rcn = upload(h, bias.data(), bias.size() * sizeof(float), (void**)&op.d_bias);
+        if (!rcn) rcn = upload(h, alpha.data(), alpha.size() * sizeof(float), (void**)&op.d_alpha);
+        return rcn;
+    }
     if (wino_eligible(h, op)) {
         op.n_tiles = (tiles16 + kWinoMaxNT - 1) / kWinoMaxNT;                 // channel groups
         const int nt = (tiles16 + op.n_tiles - 1) / op.n_tiles;               // tiles of the wide groups
         op.n_full = tiles16 - op.n_tiles * (nt - 1);                          // how many groups are wide; the others hold nt - 1
-        op.shape = ConvShape{3, 4, nt, kWinoKC, 0, 1};
+        op.shape = ConvShape{3, 4, nt, kWinoKC, 0, 0, 1};
         op.ctot = op.n_tiles * nt * 16;
         const int kc = kWinoKC;
         op.n_chunks = (op.cin_phys + kc - 1) / kc;
@@ -1030,7 +1084,8 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     a.dww = op.d_dww;
     a.dwk = op.dwk;
     a.fold = op.fold_s > 0 ? 1 : 0;
-    if (op.shape.wino) HIP_TRY(h, wino_launch(op.shape.nt, a, op.n_tiles, stream));
+    if (op.shape.nin) HIP_TRY(h, nin_launch(op.shape.nt, a, op.n_tiles, stream));
+    else if (op.shape.wino) HIP_TRY(h, wino_launch(op.shape.nt, a, op.n_tiles, stream));
     else HIP_TRY(h, conv_launch(op.shape, a, op.n_tiles, stream));
     return DCSCN_OK;
 }
@@ -1403,7 +1458,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     const Op& op = h->ops[index];
     memset(out, 0, sizeof *out);
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
-    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (op.shape.wino ? "conv_wino2" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : "depthwise");
+    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
     out->out_channels = op.cout;
@@ -1417,7 +1472,10 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     if (op.kind == OP_CONV && h->finalized) {
         const int64_t r2 = (int64_t)op.res * op.res;
         const int64_t k_exec = (int64_t)op.n_chunks * op.shape.kc;             // padded input channels
-        if (op.shape.wino) {
+        if (op.shape.nin) {
+            const int64_t tiles = (int64_t)op.n_tiles * (op.shape.nt - 1) + op.n_full;
+            out->executed_macs_per_lr_pixel = r2 * k_exec * tiles * 16;
+        } else if (op.shape.wino) {
             const int64_t tiles = (int64_t)op.n_tiles * (op.shape.nt - 1) + op.n_full;
             out->executed_macs_per_lr_pixel = r2 * 4 * k_exec * tiles * 16;    // 16 products per 2x2 outputs
         } else {
@@ -1448,6 +1506,11 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "fold_linear_tail")) {
         if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the fold_linear_tail option must be set before dcscn_finalize");
         h->fold_tail = value != 0;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "nin_gemm")) {
+        if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the nin_gemm option must be set before dcscn_finalize");
+        h->nin = value != 0;
         return DCSCN_OK;
     }
     if (!strcmp(key, "winograd")) {

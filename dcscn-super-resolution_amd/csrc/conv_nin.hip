@@ -1,0 +1,41 @@
+// conv_nin variants (conv_nin.hpp), one translation unit to parallelise the build.
+#include "conv_nin.hpp"
+
+namespace dcscn {
+
+template <int NT>
+static hipError_t nin_set_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, NinGeom<NT>::LDS_BYTES);
+}
+
+hipError_t nin_init_kernels() {
+    hipError_t e = nin_set_attr<1>();
+    if (e == hipSuccess) e = nin_set_attr<2>();
+    if (e == hipSuccess) e = nin_set_attr<3>();
+    if (e == hipSuccess) e = nin_set_attr<4>();
+    if (e == hipSuccess) e = nin_set_attr<5>();
+    return e != hipSuccess ? e : nin_set_attr<6>();
+}
+
+template <int NT>
+static hipError_t nin_launch_one(const ConvArgs& a, int n_groups, hipStream_t stream) {
+    const long long npix = (long long)a.N * a.H * a.W;
+    const dim3 grid((unsigned)((npix + NinGeom<NT>::PIX - 1) / NinGeom<NT>::PIX), (unsigned)n_groups);
+    hipLaunchKernelGGL((conv_nin<NT>), grid, dim3(256), NinGeom<NT>::LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t nin_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream) {
+    if (a.n_full < 1 || a.n_full > n_groups || (nt == 1 && a.n_full != n_groups)) return hipErrorInvalidValue;
+    switch (nt) {
+        case 1: return nin_launch_one<1>(a, n_groups, stream);
+        case 2: return nin_launch_one<2>(a, n_groups, stream);
+        case 3: return nin_launch_one<3>(a, n_groups, stream);
+        case 4: return nin_launch_one<4>(a, n_groups, stream);
+        case 5: return nin_launch_one<5>(a, n_groups, stream);
+        case 6: return nin_launch_one<6>(a, n_groups, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dcscn

@@ -56,6 +56,7 @@ struct ConvArgs {
 struct ConvShape {            // kernel variant picked by the plan
     int ks, mt, nt, kc;
     int dwk = 0;              // fused depthwise kernel size (ks == 1 only)
+    int nin = 0;              // 1: LDS-DMA staged 1x1 GEMM conv_nin (ks == 1, nt <= 6, kc == 16, 256 flat pixels per workgroup)
     int wino = 0;             // 1: Winograd F(2x2,3x3) kernel conv_wino2 (ks == 3, nt <= 3, kc == 8, 16x16 pixel tiles)
 };
 
@@ -80,6 +81,12 @@ constexpr int kWinoKC = 8;
 constexpr int kWinoMaxNT = 3;
 hipError_t wino_init_kernels();
 hipError_t wino_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
+// 1x1 convs as a GEMM over the flat pixel list (conv_nin.hpp): `nt` channel tiles of 16 per group (1..6), groups as for
+// wino_launch (args.n_full wide ones), args.wpack in the [group][chunk of 16 channels][(c & 3) * 4 + (c >> 2)][conv_ns(nt)] image.
+constexpr int kNinKC = 16;
+constexpr int kNinMaxNT = 6;
+hipError_t nin_init_kernels();
+hipError_t nin_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
 int conv_max_fused_dw_nt();
 

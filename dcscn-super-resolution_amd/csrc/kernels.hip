@@ -26,7 +26,8 @@ hipError_t conv_init_kernels() {
     if (e == hipSuccess) e = conv_init_k3();
     if (e == hipSuccess) e = conv_init_k5();
     if (e == hipSuccess) e = conv_init_k7();
-    return e != hipSuccess ? e : wino_init_kernels();
+    if (e == hipSuccess) e = wino_init_kernels();
+    return e != hipSuccess ? e : nin_init_kernels();
 }
 
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream) {
