@@ -100,13 +100,15 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
     static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
         const int slot = (wave + 4 * r) * 64 + lane;
-        const int hq = slot & 1;                             // channel quad of the chunk: lanes 2p, 2p+1 fetch 32 contiguous bytes of one pixel
         const int pix = slot >> 1;
         const int par = pix / G::PL;
         const int rem = pix - par * G::PL;
         const int row = rem / G::ROW_SLOTS;
         const int xs = rem - row * G::ROW_SLOTS;
         const int hx = 2 * xs + par;
+        // channel quad held by this slot: lanes 2p, 2p+1 fetch the 32 contiguous bytes of one pixel, in an order that
+        // alternates with (xs + row / 2) -- see the raw-patch read below
+        const int hq = (slot & 1) ^ ((xs + (row >> 1)) & 1);
         const int gy = y0 - 1 + row;
         const int gx = x0 - 1 + hx;
         a_inb[r] = slot < G::A_SLOTS && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -150,7 +152,12 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
     const int tr = 2 * wave + (lj >> 3);
     const int tc = lj & 7;
     // byte offset of the lane's raw-patch origin inside an input stage: plane pair of channel quad lk>>1, halves by lk&1
-    const int a_lane = ((2 * tr) * G::ROW_SLOTS + tc) * 32 + lk * 8;
+    // byte offset of the lane's raw-patch origin inside an input stage.  A pixel record is 32 bytes = two channel quads whose
+    // order alternates with (xs + row / 2): the 32 lanes of a ds_read_b64 group (16 tiles x the two halves of ONE quad) then
+    // touch, in the two tile rows of the wave, complementary halves of the pixel records -- all 64 banks, no conflict.
+    const int sw = (tc + tr) & 1;
+    const int a_lane_e = ((2 * tr) * G::ROW_SLOTS + tc) * 32 + (((lk >> 1) ^ sw) * 16) + (lk & 1) * 8;   // patch elements with (i/2 + jj/2) even;
+                                                                                                         // odd ones: a_lane_e ^ 16
     const int b_lane = G::B_BASE + (lk * G::NS + lj) * 4;
 
     // V = B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], on component C (channel 2k + C) of the raw patch
@@ -175,9 +182,16 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
     // raw-patch element (i, jj) of this lane's tile from an input stage.  volatile: keeps the 8-byte reads single
     // (hipcc would pair them into ds_read2_b64, which has half the LDS rate and the narrow banking)
     typedef const volatile __attribute__((address_space(3))) f32x2* lds_f32x2_ptr;
-    auto read_raw1 = [&](auto i_, auto j_, unsigned As, f32x2 (&rr)[4][4]) DCSCN_INL {
+    // (be, bo): the stage's lane bases for even / odd elements, formed per chunk (two persistent registers would not fit)
+    auto read_raw1 = [&](auto i_, auto j_, unsigned be, unsigned bo, f32x2 (&rr)[4][4]) DCSCN_INL {
         constexpr int i = decltype(i_)::value, jj = decltype(j_)::value;
-        rr[i][jj] = *(lds_f32x2_ptr)(uintptr_t)(As + ((jj & 1) * G::PL + i * G::ROW_SLOTS + (jj >> 1)) * 32);
+        const unsigned base = (((i >> 1) ^ (jj >> 1)) & 1) ? bo : be;
+        rr[i][jj] = *(lds_f32x2_ptr)(uintptr_t)(base + ((jj & 1) * G::PL + i * G::ROW_SLOTS + (jj >> 1)) * 32);
+    };
+    auto lane_bases = [&](unsigned stage_base, unsigned& be, unsigned& bo) DCSCN_INL {
+        be = stage_base + a_lane_e;
+        bo = stage_base + (a_lane_e ^ 16);
+        asm volatile("" : "+v"(be), "+v"(bo));               // keep them out of the loop-invariant (long-lived) set
     };
     // the 16*NTV MFMAs of one k-step, filter operands read PF frequencies ahead; hook(f) runs after the MFMAs of f
     auto mfma_step = [&](const float* Bs, const float (&v)[16], auto&& hook) DCSCN_INL {
@@ -217,16 +231,21 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x2 rr[4][4];
-    static_for<0, 4>([&](auto i_) DCSCN_INL {
-        static_for<0, 4>([&](auto j_) DCSCN_INL { read_raw1(i_, j_, lds0 + a_lane, rr); });
-    });
+    {
+        unsigned be, bo;
+        lane_bases(lds0, be, bo);
+        static_for<0, 4>([&](auto i_) DCSCN_INL {
+            static_for<0, 4>([&](auto j_) DCSCN_INL { read_raw1(i_, j_, be, bo, rr); });
+        });
+    }
     __syncthreads();                                          // every wave holds its patch of chunk 0: input stage 0 may be refilled
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
         const unsigned sb = chunk & 1;
         const int cb = chunk + 1 < last ? chunk + 1 : last;   // filters to fetch
         const int ca = chunk + 2 < last ? chunk + 2 : last;   // input to fetch
         const float* Bs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + b_lane + sb * G::B_BYTES);
-        const unsigned An = lds0 + a_lane + (sb ^ 1) * G::A_BYTES;
+        const unsigned An = lds0 + (sb ^ 1) * G::A_BYTES;
+        unsigned be = 0, bo = 0;
         float v[16];
         transform(std::integral_constant<int, 0>{}, rr, v);
         mfma_step(Bs, v, [&](auto f_) DCSCN_INL {
@@ -242,9 +261,10 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
         mfma_step(Bs + 4 * G::NS, v, [&](auto f_) DCSCN_INL {
             constexpr int f = decltype(f_)::value;
             // raw patch of the next chunk, two elements behind each of the last 8 frequencies
+            if constexpr (f == 7) lane_bases(An, be, bo);
             if constexpr (f >= 8) {
-                read_raw1(std::integral_constant<int, (2 * (f - 8)) / 4>{}, std::integral_constant<int, (2 * (f - 8)) % 4>{}, An, rr);
-                read_raw1(std::integral_constant<int, (2 * (f - 8) + 1) / 4>{}, std::integral_constant<int, (2 * (f - 8) + 1) % 4>{}, An, rr);
+                read_raw1(std::integral_constant<int, (2 * (f - 8)) / 4>{}, std::integral_constant<int, (2 * (f - 8)) % 4>{}, be, bo, rr);
+                read_raw1(std::integral_constant<int, (2 * (f - 8) + 1) / 4>{}, std::integral_constant<int, (2 * (f - 8) + 1) % 4>{}, be, bo, rr);
             }
         });
         if constexpr (ABL != 2 && ABL != 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

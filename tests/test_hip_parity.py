@@ -46,21 +46,31 @@ def test_config_48x48(oracle, name, winograd):
     _check(oracle, name, CONFIGS[name], n, 48, 48, winograd=winograd)
 
 
+@pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("winograd", [True, False])
-def test_residual_branch_relative_error(oracle, winograd):
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_residual_branch_relative_error(oracle, name, winograd, fold):
     """The synthetic weights scale the last conv by 0.01, which would hide upstream errors behind the
     bicubic term.  Here the last conv is NOT scaled and x2 = 0, so y is the bare network branch; its
-    error is bounded relative to its own magnitude (f32 accumulation over K <= 1764 terms)."""
-    cfg = oracle.make_config()
+    error is bounded relative to its own magnitude (f32 accumulation over K <= 1764 terms) -- for EVERY
+    BASELINE config and shipped topology, on the Winograd / direct kernels, folded tail and layer by layer."""
+    cfg = oracle.make_config(**CONFIGS[name])
     weights = oracle.synthetic_weights(cfg, seed=7)
-    weights["R-CNN1/conv_W"] = weights["R-CNN1/conv_W"] * 100.0
-    x, _ = synthetic_batch(2, 48, 48, 2, seed=8)
-    x2 = np.zeros((2, 96, 96, 1), np.float32)
+    last = "R-CNN%d" % cfg["reconstruct_layers"]
+    for leaf in ("conv_W", "pointwise_W"):
+        if last + "/" + leaf in weights:
+            weights[last + "/" + leaf] = weights[last + "/" + leaf] * 100.0
+    s = cfg["scale"]
+    x, _ = synthetic_batch(2, 48, 48, s, seed=8)
+    x2 = np.zeros((2, 48 * s, 48 * s, 1), np.float32)
     ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
-    with _engine(cfg, weights, winograd) as eng:
-        y = eng.forward(x, x2)
+    from dcscn_amd import engine
+    eng = engine.Engine(cfg, device=0)
+    eng.load_weights(weights, winograd=winograd, fold_tail=fold)
+    y = eng.forward(x, x2)
+    eng.close()
     rel = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
-    print("winograd=%s residual-branch relative error %.3g (max|y| %.3g)" % (winograd, rel, np.max(np.abs(ref))))
+    print("%s winograd=%s fold=%s residual-branch relative error %.3g (max|y| %.3g)" % (name, winograd, fold, rel, np.max(np.abs(ref))))
     assert rel <= 5e-6
 
 
