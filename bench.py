@@ -85,9 +85,10 @@ def pmc_replay(dom_ms, nin_ms, algorithmic_bytes):
                                    "note": "counter bytes (corrected) / this run's kernel time; the 3x3 stack is a dense f32 "
                                            "contraction (AI 117-404 FLOP/B): MFMA bound, not HBM bound"}
         for name, k in kernels.items():
-            if name.startswith("conv_igemm<1,") and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
+            if (name.startswith("conv_nin<") or name.startswith("conv_igemm<1,")) and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
                 active = k["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
-                ns["nin_1x1"] = {"mfma_util": round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * active), 4),
+                ns["nin_1x1"] = {"kernel": name, "mfma_util": round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * active), 4),
+                                 "lds_bank_conflict_frac": round(k["SQ_LDS_BANK_CONFLICT"] / k["SQ_LDS_IDX_ACTIVE"], 4) if k.get("SQ_LDS_IDX_ACTIVE") else None,
                                  "ms_per_step": round(nin_ms, 4),
                                  "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x active cycles), fused B1+A1 GEMM"}
             if name.startswith("conv_wino") and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
@@ -255,7 +256,7 @@ def main():
                       % (o["name"], o["kernel"], o["kernel_size"], o["in_channels"], o["out_channels"], o["resolution"],
                          o["mt"], o["nt"], o["kc"], o["n_tiles"], ms, fl / (ms * 1e-3) / 1e12 if ms else 0,
                          fx / (ms * 1e-3) / 1e12 if ms else 0, by / (ms * 1e-3) / 1e9 if ms else 0), file=sys.stderr)
-        nin_ms = sum(ms for o, ms in zip(ops, per_op_ms) if o["kernel"] == "conv_igemm" and o["kernel_size"] == 1)
+        nin_ms = sum(ms for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_nin") and o["kernel_size"] == 1)
         full_workload = n == PATCHES_PER_GPU and not args.no_winograd
         traffic, north_star = pmc_replay(dom_ms, nin_ms, dom_bytes) if full_workload else (None, None)
         graph = ("linear tail (Up-PS conv + depth_to_space + R-CNN1) folded into one 5x5 conv -- library default, include/dcscn.h fold_linear_tail"
