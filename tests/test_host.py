@@ -171,6 +171,53 @@ def test_ssim_vectorised_equals_per_column_loop():
         util._ssim_last_axis_channels(a[:10], b[:10], 255, 1.5, 0.01, 0.03)
 
 
+def test_ssim_against_a_first_principles_restatement():
+    """scikit-image is not installable here, so SSIM is pinned to its PUBLISHED algorithm instead (Wang et al. 2004 as
+    implemented by skimage.metrics.structural_similarity with win_size=11, gaussian_weights=True, sigma=1.5,
+    use_sample_covariance=True, K1=.01, K2=.03, data_range=255 -- the call at utilty.py:533-535), restated here with
+    nothing but numpy: an explicit normalised Gaussian of radius int(3.5*1.5+0.5)=5, scipy's 'reflect' (half-sample
+    symmetric) boundary written out by hand, sample-covariance factor NP/(NP-1) with NP = 11 (1-D windows: the
+    multichannel=True quirk makes every image COLUMN a 1-D signal), 5 border samples cropped from the mean."""
+    from dcscn_amd import imaging as util
+    rng = np.random.default_rng(11)
+    a = rng.uniform(0, 255, (45, 9)).round()
+    b = np.clip(a + rng.normal(0, 12, a.shape), 0, 255).round()
+
+    sigma, radius = 1.5, 5
+    g = np.exp(-0.5 * (np.arange(-radius, radius + 1) / sigma) ** 2)
+    g /= g.sum()
+
+    def filt(x):                                  # 1-D correlation with reflect padding: (d c b a | a b c d | d c b a)
+        n = len(x)
+        out = np.empty(n)
+        for i in range(n):
+            acc = 0.0
+            for k in range(-radius, radius + 1):
+                j = i + k
+                while j < 0 or j >= n:
+                    j = -j - 1 if j < 0 else 2 * n - 1 - j
+                acc += g[k + radius] * x[j]
+            out[i] = acc
+        return out
+
+    c1, c2, cov_norm = (0.01 * 255) ** 2, (0.03 * 255) ** 2, 11.0 / 10.0
+    per_column = []
+    for col in range(a.shape[1]):
+        x, y = a[:, col].astype(np.float64), b[:, col].astype(np.float64)
+        ux, uy = filt(x), filt(y)
+        vx = cov_norm * (filt(x * x) - ux * ux)
+        vy = cov_norm * (filt(y * y) - uy * uy)
+        vxy = cov_norm * (filt(x * y) - ux * uy)
+        s_map = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
+        per_column.append(s_map[radius:-radius].mean())
+    want = float(np.mean(per_column))
+    got = util._ssim_last_axis_channels(a, b, 255, 1.5, 0.01, 0.03)
+    assert abs(got - want) < 1e-12, (got, want)
+    # and through the public entry point (rint / clip / shave as utilty.py:501-527; border 2 here)
+    psnr, ssim = util.compute_psnr_and_ssim(a[:, :, None], b[:, :, None], border_size=0)
+    assert abs(ssim - want) < 1e-12
+
+
 def test_bicubic_goldens_through_the_host_glue(oracle):
     """evaluate_bicubic's recipe with the package's own helpers reproduces the oracle's numbers."""
     from dcscn_amd import imaging as util
