@@ -156,6 +156,7 @@ struct dcscn_ctx {
     int64_t workspace_budget = (int64_t)48 << 30;   // clamped to a share of the free device memory in dcscn_create
     bool budget_user_set = false;
     hipEvent_t done_ev = nullptr;            // recorded behind the last forward, on the stream it ran on
+    std::vector<hipEvent_t> host_ev;         // dcscn_forward: one per chunk of the host-buffer pipeline
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     bool profile = false;
@@ -1550,6 +1551,52 @@ static int ensure_io(dcscn_ctx* h, size_t lr_floats, size_t hr_floats) {
     return DCSCN_OK;
 }
 
+// Host-buffer forward in up to 4 chunks of images: the upload of chunk i+1 and the download of chunk i-1 run while chunk i
+// computes (blocking hipMemcpy on pageable user memory runs at PCIe speed and overlaps kernels of the handle's stream;
+// hipMemcpyAsync would stage pageable buffers at ~3 GB/s on this stack).  x2 == nullptr: x2 = bicubic(x) on the device.
+static int forward_host_chunked(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, int height, int width) {
+    const int s = h->cfg.scale;
+    const size_t lr1 = (size_t)height * width, hr1 = lr1 * s * s;
+    int rc = ensure_io(h, lr1 * n, hr1 * n);
+    if (rc) return rc;
+    const int chunks = (hr1 * n * sizeof(float) >= ((size_t)8 << 20) && n >= 8) ? 4 : 1;
+    while ((int)h->host_ev.size() < chunks) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->host_ev.push_back(e);
+    }
+    const bool trace = getenv("DCSCN_TRACE_HOST") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    int begin[5];
+    for (int i = 0; i <= chunks; ++i) begin[i] = (int)((int64_t)n * i / chunks);
+    // the first chunk must be the largest: it sizes the workspace carve the later ones reuse
+    auto span = [&](int i, int* b, int* cnt) { *b = begin[chunks - 1 - i] ; *cnt = begin[chunks - i] - begin[chunks - 1 - i]; };
+    auto download = [&](int i) -> int {
+        int b, cnt;
+        span(i, &b, &cnt);
+        HIP_TRY(h, hipEventSynchronize(h->host_ev[i]));
+        HIP_TRY(h, hipMemcpy(y + (size_t)b * hr1, h->io_y + (size_t)b * hr1, (size_t)cnt * hr1 * sizeof(float), hipMemcpyDeviceToHost));
+        return DCSCN_OK;
+    };
+    for (int i = 0; i < chunks; ++i) {
+        int b, cnt;
+        span(i, &b, &cnt);
+        if (cnt > 0) {
+            HIP_TRY(h, hipMemcpy(h->io_x + (size_t)b * lr1, x + (size_t)b * lr1, (size_t)cnt * lr1 * sizeof(float), hipMemcpyHostToDevice));
+            if (x2) HIP_TRY(h, hipMemcpy(h->io_x2 + (size_t)b * hr1, x2 + (size_t)b * hr1, (size_t)cnt * hr1 * sizeof(float), hipMemcpyHostToDevice));
+            else rc = resize_device(h, h->io_x + (size_t)b * lr1, h->io_x2 + (size_t)b * hr1, cnt, height, width, height * s, width * s, h->stream);   // DCSCN.py:552-554
+            if (!rc) rc = run_forward(h, h->io_x + (size_t)b * lr1, h->io_x2 + (size_t)b * hr1, h->io_y + (size_t)b * hr1, cnt, height, width, h->stream);
+            if (rc) return rc;
+        }
+        HIP_TRY(h, hipEventRecord(h->host_ev[i], h->stream));
+        if (i > 0 && (rc = download(i - 1))) return rc;
+    }
+    if ((rc = download(chunks - 1))) return rc;
+    if (trace) fprintf(stderr, "dcscn_forward: %d chunk(s), %.2f ms\n", chunks, now() - t0);
+    return DCSCN_OK;
+}
+
 int dcscn_forward(dcscn_handle h, const float* x, const float* x2, float* y, int n, int height, int width) {
     if (!h) return DCSCN_ERR_INVALID_ARG;
     if (!h->finalized) return fail(h, DCSCN_ERR_STATE, "dcscn_forward before dcscn_finalize");
@@ -1557,25 +1604,7 @@ int dcscn_forward(dcscn_handle h, const float* x, const float* x2, float* y, int
     if (n == 0) return DCSCN_OK;
     if (!x || !x2 || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
     HIP_TRY(h, hipSetDevice(h->device));
-    const int s = h->cfg.scale;
-    const size_t lr = (size_t)n * height * width, hr = lr * s * s;
-    int rc = ensure_io(h, lr, hr);
-    if (rc) return rc;
-    // Blocking hipMemcpy on pageable user memory, not hipMemcpyAsync: the async form stages pageable buffers at
-    // ~3 GB/s on this stack (30 ms per 85 MB), the blocking one runs at PCIe speed (< 1 ms per 38 MB).
-    const bool trace = getenv("DCSCN_TRACE_HOST") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
-    HIP_TRY(h, hipMemcpy(h->io_x, x, lr * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->io_x2, x2, hr * sizeof(float), hipMemcpyHostToDevice));
-    const double t1 = now();
-    rc = run_forward(h, h->io_x, h->io_x2, h->io_y, n, height, width, h->stream);
-    if (rc) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const double t2 = now();
-    HIP_TRY(h, hipMemcpy(y, h->io_y, hr * sizeof(float), hipMemcpyDeviceToHost));
-    if (trace) fprintf(stderr, "dcscn_forward: H2D %.2f ms, kernels %.2f ms, D2H %.2f ms\n", t1 - t0, t2 - t1, now() - t2);
-    return DCSCN_OK;
+    return forward_host_chunked(h, x, x2, y, n, height, width);
 }
 
 int dcscn_resample_table(int in_size, int out_size, int* ksize, int* bounds, double* weights, int capacity) {
@@ -1627,17 +1656,7 @@ int dcscn_forward_lr(dcscn_handle h, const float* x, float* y, int n, int height
     if (n == 0) return DCSCN_OK;
     if (!x || !y) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
     HIP_TRY(h, hipSetDevice(h->device));
-    const int s = h->cfg.scale;
-    const size_t lr = (size_t)n * height * width, hr = lr * s * s;
-    int rc = ensure_io(h, lr, hr);
-    if (rc) return rc;
-    HIP_TRY(h, hipMemcpy(h->io_x, x, lr * sizeof(float), hipMemcpyHostToDevice));
-    rc = resize_device(h, h->io_x, h->io_x2, n, height, width, height * s, width * s, h->stream);   // DCSCN.py:552-554
-    if (!rc) rc = run_forward(h, h->io_x, h->io_x2, h->io_y, n, height, width, h->stream);
-    if (rc) return rc;
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(y, h->io_y, hr * sizeof(float), hipMemcpyDeviceToHost));
-    return DCSCN_OK;
+    return forward_host_chunked(h, x, nullptr, y, n, height, width);
 }
 
 // do()'s self-ensemble for the image pair already in io_x / io_x2; leaves the float64 mean in ens_out (enqueued, not synchronised)
@@ -1869,6 +1888,7 @@ int dcscn_destroy(dcscn_handle h) {
     if (h->has_last) (void)hipStreamSynchronize(h->last_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->done_ev) (void)hipEventDestroy(h->done_ev);
+    for (hipEvent_t e : h->host_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (void* p : h->device_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
