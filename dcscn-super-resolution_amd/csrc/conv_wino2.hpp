@@ -134,19 +134,20 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
         }
     };
 
-    // clear both input stages once (zero padding slots are never written again)
-    {
-        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = tid; i < 2 * G::A_BYTES / 16; i += G::THREADS) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + 16 * i) = z;
-        __syncthreads();
-    }
+    // SAME zero padding: the slots of halo pixels outside the image are never written by the DMA (their lanes are masked
+    // off) -- the owning lane clears them once, in both stages.  Interior tiles clear nothing.  (Channel-tail slots of
+    // the last chunk keep the data of chunk n-3: a Winograd layer has >= 4 chunks, so that is real, finite data.)
+    static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL {
+        constexpr int r = decltype(r_)::value;
+        const int slot = (wave + 4 * r) * 64 + lane;
+        if (!a_inb[r] && slot < G::A_SLOTS) {
+            const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + 16 * slot) = z;
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::A_BYTES + 16 * slot) = z;
+        }
+    });
 
     f32x4 acc[16][NTV];
-    static_for<0, 16>([&](auto f_) DCSCN_INL {
-        static_for<0, NTV>([&](auto n_) DCSCN_INL {
-            acc[decltype(f_)::value][decltype(n_)::value] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        });
-    });
 
     // this lane's Winograd tile: rows 2w, 2w+1 of the 8x8 tile grid, 8 tiles per row
     const int tr = 2 * wave + (lj >> 3);
@@ -228,6 +229,13 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
     static_for<0, G::B_ROUNDS>([&](auto r_) DCSCN_INL { dma_b(r_, 0, 0); });
     static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL { dma_a(r_, 0, 0); });
     static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL { dma_a(r_, last < 1 ? last : 1, 1); });
+    // the accumulators are cleared while the first chunks are in flight
+    static_for<0, 16>([&](auto f_) DCSCN_INL {
+        static_for<0, NTV>([&](auto n_) DCSCN_INL {
+            acc[decltype(f_)::value][decltype(n_)::value] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        });
+    });
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x2 rr[4][4];

@@ -78,3 +78,24 @@ def test_evaluate_rgb_rejects_unaligned_images(tmp_path):
         m._ready_engine().evaluate_rgb(np.zeros((31, 40, 3), np.uint8))
     assert type(e.value).__name__ == "EngineError" and e.value.status == 1
     m.close()
+
+
+def test_do_for_file_device_colour_path_writes_the_same_images(tmp_path):
+    """sr.py's work (do_for_file, DCSCN.py:588-614) through dcscn_sr_rgb: same output files, same pixels as the host colour path."""
+    from PIL import Image
+    g, m = _model(tmp_path, "L7_x2")
+    src = os.path.join(GOLDEN, "set5", g["files"][2])
+    crop = tmp_path / "in.png"
+    Image.open(src).convert("RGB").crop((0, 0, 64, 48)).save(crop)
+    m.do_for_file(str(crop), str(tmp_path / "dev"))
+    assert m._device_colour_path(np.asarray(Image.open(crop)))
+    # host path: force it by pretending the resampling method differs only in name
+    m._device_colour_path = lambda image: False
+    m.do_for_file(str(crop), str(tmp_path / "host"))
+    names = sorted(os.listdir(tmp_path / "dev" / m.name))
+    assert names == sorted(os.listdir(tmp_path / "host" / m.name)) and "in_result.png" in names and "in_result_y.png" in names
+    for nme in names:
+        a = np.asarray(Image.open(tmp_path / "dev" / m.name / nme))
+        b = np.asarray(Image.open(tmp_path / "host" / m.name / nme))
+        assert np.array_equal(a, b), nme
+    m.close()
