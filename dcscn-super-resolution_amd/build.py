@@ -21,7 +21,11 @@ HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "conv_igemm.hpp", "conv_
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-source extra flags (see the comment at the top of conv_wino2.hip)
-EXTRA_FLAGS = {"conv_wino2.hip": ["-fno-slp-vectorize"], "conv_nin.hip": ["-fno-slp-vectorize"], "color.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"conv_wino2.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"],
+               "conv_nin.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "color.hip": ["-ffp-contract=off"]}
+# kernels that sit at the VGPR limit by design (192 accumulators + operands): a register spill inside their K loop also
+# breaks the hand-counted vmcnt accounting of the LDS-DMA pipeline, so a build that spills is rejected, not shipped
+NO_SCRATCH = ("conv_wino2.hip", "conv_nin.hip")
 
 
 def hipcc_path():
@@ -42,6 +46,13 @@ def _run(cmd):
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise RuntimeError("command failed (%d): %s\n%s" % (proc.returncode, " ".join(cmd), proc.stdout))
+    if any(cmd[-3].endswith(n) for n in NO_SCRATCH if len(cmd) >= 3):
+        import re
+        bad = [ln for ln in proc.stdout.splitlines() if re.search(r"(ScratchSize \[bytes/lane\]|VGPRs Spill): [1-9]", ln)]
+        if bad:
+            os.remove(cmd[-1])
+            raise RuntimeError("register spill in a kernel that must not spill (%s):\n%s" % (cmd[-3], "\n".join(bad[:6])))
+        return ""
     return proc.stdout
 
 

@@ -223,8 +223,9 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
     // ---- K loop ----
     // chunk c reads filter stage c&1 (k-steps 0, 1) and, during k-step 1, the raw patch of chunk c+1 from input stage
     // (c+1)&1; it issues the DMA of filters c+1 -> filter stage (c+1)&1 (last read in chunk c-1) and of input c+2 -> input
-    // stage c&1 (last read, as a raw patch, during chunk c-1).  Chunk indices are clamped instead of branched on: the
-    // redundant copies of the last iterations land in stages nobody reads again.
+    // stage c&1 (last read, as a raw patch, during chunk c-1).  The last iterations skip the copies that have no chunk
+    // left to fetch (uniform branches; 1 filter block and 2 input tiles per workgroup -- a quarter of the input DMA of an
+    // 8-chunk layer); the raw-patch read of the last iteration lands on stale data and is not used.
     const int last = a.n_chunks - 1;
     static_for<0, G::B_ROUNDS>([&](auto r_) DCSCN_INL { dma_b(r_, 0, 0); });
     static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL { dma_a(r_, 0, 0); });
@@ -249,8 +250,8 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
     __syncthreads();                                          // every wave holds its patch of chunk 0: input stage 0 may be refilled
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
         const unsigned sb = chunk & 1;
-        const int cb = chunk + 1 < last ? chunk + 1 : last;   // filters to fetch
-        const int ca = chunk + 2 < last ? chunk + 2 : last;   // input to fetch
+        const bool more_b = chunk + 1 <= last;               // filters of chunk c+1 / input of chunk c+2 exist (wave uniform)
+        const bool more_a = chunk + 2 <= last;
         const float* Bs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + b_lane + sb * G::B_BYTES);
         const unsigned An = lds0 + (sb ^ 1) * G::A_BYTES;
         unsigned be = 0, bo = 0;
@@ -260,9 +261,9 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
             constexpr int f = decltype(f_)::value;
             // one DMA piece behind each of the first B_ROUNDS + A_ROUNDS frequencies
             if constexpr (f >= 1 && f <= G::B_ROUNDS) {
-                if constexpr (ABL != 1 && ABL != 3) dma_b(std::integral_constant<int, f - 1>{}, cb, sb ^ 1);
+                if constexpr (ABL != 1 && ABL != 3) { if (more_b) dma_b(std::integral_constant<int, f - 1>{}, chunk + 1, sb ^ 1); }
             } else if constexpr (f > G::B_ROUNDS && f <= G::B_ROUNDS + G::A_ROUNDS) {
-                if constexpr (ABL != 1 && ABL != 4) dma_a(std::integral_constant<int, f - 1 - G::B_ROUNDS>{}, ca, sb);
+                if constexpr (ABL != 1 && ABL != 4) { if (more_a) dma_a(std::integral_constant<int, f - 1 - G::B_ROUNDS>{}, chunk + 2, sb); }
             }
         });
         transform(std::integral_constant<int, 1>{}, rr, v);
