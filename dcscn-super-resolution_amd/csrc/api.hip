@@ -109,6 +109,10 @@ struct Op {
     float* d_alpha = nullptr;
     int32_t* d_map = nullptr;
     float* d_dww = nullptr;
+    // multi-source input (densify_features): the K axis is the concatenation of these dense tensors
+    std::vector<std::pair<int, int>> multi;   // (buffer, physical channels = pad4)
+    std::vector<NinSrcQuad> h_srctab;         // host copy of the quad table, refilled whenever the arena is re-carved
+    NinSrcQuad* d_srctab = nullptr;
 };
 
 }  // namespace
@@ -161,6 +165,10 @@ struct dcscn_ctx {
     bool has_last = false;
     bool profile = false;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
+    bool dense_features = true;              // per-layer feature buffers + multi-source NIN GEMM instead of one concat tensor (densify_features)
+    int concat_buf = -1;                     // build_graph: the skip-concat buffer, its slices (offset, logical width)
+    std::vector<std::pair<int, int>> concat_slices;
+    uint64_t carve_gen = 0, tables_gen = 0;  // arena carve generation / generation the multi-source tables were filled for
     bool nin = true;                         // wide 1x1 convs on the LDS-DMA staged GEMM (conv_nin); option "nin_gemm" 0 = conv_igemm
     bool fold_tail = true;                   // graph rewrite of the linear tail, see fold_linear_tail(); option "fold_linear_tail" 0 = layer by layer
     bool spatial_tiling = true;              // images larger than one pass are cut into haloed windows (run_tiled)
@@ -468,6 +476,8 @@ int build_graph(dcscn_ctx* h) {
         total += h->sched[i];
     }
     const int concat = new_buf(h, concat_stride, 1);
+    h->concat_buf = concat;
+    for (int i = 0; i < c.layers; ++i) h->concat_slices.push_back({slice_off[i], h->sched[i]});
 
     // feature extraction, DCSCN.py:240-256
     Src src;
@@ -995,6 +1005,7 @@ int ensure_workspace(dcscn_ctx* h, int nb, int H, int W, hipStream_t stream) {
     // padding channels that no kernel writes (depth_to_space outputs with C % 4 != 0) must hold
     // finite values: clear the bytes of the new carve
     HIP_TRY(h, hipMemsetAsync(h->arena, 0, total, stream));
+    h->carve_gen += 1;
     h->lay_n = nb;
     h->lay_h = H;
     h->lay_w = W;
@@ -1085,6 +1096,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     a.dww = op.d_dww;
     a.dwk = op.dwk;
     a.fold = op.fold_s > 0 ? 1 : 0;
+    a.srctab = op.multi.empty() ? nullptr : op.d_srctab;
     if (op.shape.nin) HIP_TRY(h, nin_launch(op.shape.nt, a, op.n_tiles, stream));
     else if (op.shape.wino) HIP_TRY(h, wino_launch(op.shape.nt, a, op.n_tiles, stream));
     else HIP_TRY(h, conv_launch(op.shape, a, op.n_tiles, stream));
@@ -1204,6 +1216,22 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         rc = ensure_workspace(h, nb, H, W, stream);
     }
     if (rc) return rc;
+    if (h->tables_gen != h->carve_gen) {
+        // the multi-source tables hold arena addresses: refill them behind the re-carve, on the launch stream
+        for (Op& op : h->ops) {
+            if (op.multi.empty()) continue;
+            size_t q = 0;
+            for (const auto& sg : op.multi) {
+                const char* base = reinterpret_cast<const char*>(buf_ptr(h, sg.first));
+                const unsigned stride = (unsigned)(h->bufs[sg.first].stride * sizeof(float));
+                for (int c4 = 0; c4 < sg.second / 4 && q < op.h_srctab.size(); ++c4, ++q)
+                    op.h_srctab[q] = NinSrcQuad{(unsigned long long)(uintptr_t)(base + 16 * c4), stride, 1u};
+            }
+            for (; q < op.h_srctab.size(); ++q) op.h_srctab[q] = NinSrcQuad{0, 0, 0};
+            HIP_TRY(h, hipMemcpyAsync(op.d_srctab, op.h_srctab.data(), op.h_srctab.size() * sizeof(NinSrcQuad), hipMemcpyHostToDevice, stream));
+        }
+        h->tables_gen = h->carve_gen;
+    }
     const int s = h->cfg.scale;
     const int batches = (n + nb - 1) / nb;
     const int nops = (int)h->ops.size();
@@ -1426,6 +1454,49 @@ int dcscn_set_tensor(dcscn_handle h, const char* name, const float* data, const 
     return DCSCN_OK;
 }
 
+// ---- dense per-layer feature buffers ------------------------------------------------------------------
+// build_graph lets every feature layer store into its slice of ONE [n, H, W, sum pad4(C_i)] tensor, which makes tf.concat
+// free -- but a narrow slice of a wide NHWC record is a partial, misaligned cache-line access per pixel, for the layer that
+// writes it and for the layer that reads it (measured on the c-DCSCN nets: two structurally opposite kernels took exactly the
+// same time).  When every consumer of the whole concat is a conv_nin launch (A1 || B1, or the non-NIN "C"
+// layer), this pass gives each feature layer its own dense [n, H, W, pad4(C_i)] buffer and hands the consumers the list
+// of buffers: conv_nin walks them through a per-quad source table (conv_nin.hpp: MULTI).  The virtual channel order is
+// unchanged, so chan_map and the packed filters stay as they are.
+void densify_features(dcscn_ctx* h) {
+    if (!h->dense_features || h->concat_buf < 0) return;
+    const int cat = h->concat_buf;
+    const int cat_stride = h->bufs[cat].stride;
+    std::vector<int> consumers;
+    for (size_t i = 0; i < h->ops.size(); ++i) {
+        const Op& op = h->ops[i];
+        if (op.in_buf != cat) continue;
+        bool slice = false;
+        for (const auto& sl : h->concat_slices) slice = slice || (op.in_off == sl.first && op.cin_phys == pad4(sl.second));
+        if (slice && !(op.in_off == 0 && op.cin_phys == cat_stride)) continue;                 // a feature layer reading its predecessor
+        if (op.in_off != 0 || op.cin_phys != cat_stride || !nin_eligible(h, op) || (size_t)((op.cin_phys + 15) / 16) * 64 > 16 * 1024) return;
+        consumers.push_back((int)i);
+    }
+    if (consumers.empty() || h->concat_slices.size() < 2) return;
+    std::vector<int> nb;
+    // (row strides padded to 64 / 128 bytes were measured: noise on the wide nets, 3-18 % slower on the narrow ones)
+    for (const auto& sl : h->concat_slices) nb.push_back(new_buf(h, pad4(sl.second), 1));
+    for (Op& op : h->ops) {
+        for (size_t k = 0; k < h->concat_slices.size(); ++k) {
+            const int off = h->concat_slices[k].first, w4 = pad4(h->concat_slices[k].second);
+            for (int o = 0; o < 2; ++o)
+                if (op.out_buf[o] == cat && op.out_off[o] == off) { op.out_buf[o] = nb[k]; op.out_off[o] = 0; }
+            if (op.in_buf == cat && op.in_off == off && op.cin_phys == w4 && !(off == 0 && w4 == cat_stride)) { op.in_buf = nb[k]; op.in_off = 0; }
+        }
+    }
+    for (int ci : consumers) {
+        Op& op = h->ops[ci];
+        for (size_t k = 0; k < nb.size(); ++k) op.multi.push_back({nb[k], pad4(h->concat_slices[k].second)});
+    }
+    bool used = false;
+    for (const Op& o : h->ops) used = used || (o.multi.empty() && o.in_buf == cat) || o.out_buf[0] == cat || o.out_buf[1] == cat;
+    if (!used) h->bufs[cat].stride = 0;                         // the concat tensor no longer exists
+}
+
 int dcscn_finalize(dcscn_handle h) {
     if (!h) return DCSCN_ERR_INVALID_ARG;
     if (h->finalized) return DCSCN_OK;
@@ -1433,9 +1504,15 @@ int dcscn_finalize(dcscn_handle h) {
         if (!t.set) return fail(h, DCSCN_ERR_MISSING_TENSOR, "variable '%s' was never set", t.name.c_str());
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->fold_tail) fold_linear_tail(h);      // silently keeps the layer-by-layer graph where it does not apply
+    densify_features(h);
     for (Op& op : h->ops) {
         int rc = finalize_op(h, op);
         if (rc) return rc;
+        if (!op.multi.empty()) {
+            op.h_srctab.assign((size_t)4 * op.n_chunks, NinSrcQuad{0, 0, 0});
+            rc = upload(h, op.h_srctab.data(), op.h_srctab.size() * sizeof(NinSrcQuad), (void**)&op.d_srctab);
+            if (rc) return rc;
+        }
     }
     h->prof_ms.assign(h->ops.size(), 0.0);
     h->finalized = true;
@@ -1507,6 +1584,11 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "fold_linear_tail")) {
         if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the fold_linear_tail option must be set before dcscn_finalize");
         h->fold_tail = value != 0;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "dense_features")) {
+        if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the dense_features option must be set before dcscn_finalize");
+        h->dense_features = value != 0;
         return DCSCN_OK;
     }
     if (!strcmp(key, "nin_gemm")) {

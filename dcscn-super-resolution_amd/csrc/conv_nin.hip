@@ -3,9 +3,14 @@
 
 namespace dcscn {
 
+constexpr int kNinMaxTable = 16 * 1024;          // LDS bytes for the multi-source quad table: 1024 quads = 4096 input channels
+
 template <int NT>
 static hipError_t nin_set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, NinGeom<NT>::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NinGeom<NT>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               NinGeom<NT>::LDS_BYTES + kNinMaxTable);
 }
 
 hipError_t nin_init_kernels() {
@@ -21,7 +26,13 @@ template <int NT>
 static hipError_t nin_launch_one(const ConvArgs& a, int n_groups, hipStream_t stream) {
     const long long npix = (long long)a.N * a.H * a.W;
     const dim3 grid((unsigned)((npix + NinGeom<NT>::PIX - 1) / NinGeom<NT>::PIX), (unsigned)n_groups);
-    hipLaunchKernelGGL((conv_nin<NT>), grid, dim3(256), NinGeom<NT>::LDS_BYTES, stream, a);
+    if (a.srctab) {
+        const size_t table = (size_t)a.n_chunks * 64;
+        if (table > (size_t)kNinMaxTable) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((conv_nin<NT, true>), grid, dim3(256), NinGeom<NT>::LDS_BYTES + table, stream, a);
+    } else {
+        hipLaunchKernelGGL((conv_nin<NT, false>), grid, dim3(256), NinGeom<NT>::LDS_BYTES, stream, a);
+    }
     return hipGetLastError();
 }
 

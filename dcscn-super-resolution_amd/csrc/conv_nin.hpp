@@ -21,11 +21,26 @@
 //   multiplied into accumulator columns nobody stores (pixels) or by zero filter rows (channels; the stages are cleared
 //   once so that "stale" is finite).
 //
+// MULTI (multi-source input): the K axis is the concatenation of several dense NHWC tensors (the per-layer buffers of the
+// feature stack, api.hip: densify_features) instead of one wide concat tensor.  A device table with one entry per 16-byte
+// channel quad of the virtual concat -- {pointer to that quad of pixel 0, pixel stride in bytes, valid} -- is copied to
+// LDS once; a DMA lane always serves the same quad position (lane & 3) of its pixels, reads its entry per chunk and
+// forms a 64-bit source address.  Nothing else changes: the LDS image, the filter image and the MFMA loop are the same.
+//
 // Epilogue = conv_igemm's: bias, activator, two destinations (B1 -> T1, A1 -> its slice of Concat2), float4 NHWC stores.
 #pragma once
 #include "conv_wino2.hpp"
 
 namespace dcscn {
+
+// LDS-DMA with a per-lane 64-bit source address (conv_wino2.hpp: glds16 takes an SGPR base + 32-bit lane offset)
+__device__ __forceinline__ void glds16v(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
 
 template <int NT>
 struct NinGeom {
@@ -48,7 +63,7 @@ struct NinGeom {
     static constexpr int A_ROUNDS = A_DMA / 4;
 };
 
-template <int NT, int NTV>
+template <int NT, int NTV, bool MULTI>
 __device__ __forceinline__ void conv_nin_body(const ConvArgs& a, float* smem, long long pix0, int ntile) {
     using G = NinGeom<NT>;
     const int tid = threadIdx.x;
@@ -86,16 +101,32 @@ __device__ __forceinline__ void conv_nin_body(const ConvArgs& a, float* smem, lo
             else if (piece * 1024 + lane * 16 < G::B_BYTES) glds16(src, b_off, dst);     // partial last piece
         }
     };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef const volatile __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
+    u32x4 ent = {0u, 0u, 0u, 0u};
+    auto load_ent = [&](int chunk) DCSCN_INL {
+        if constexpr (MULTI) ent = *(lds_u32x4_ptr)(uintptr_t)(lds0 + G::LDS_BYTES + (unsigned)(chunk * 4 + (lane & 3)) * 16u);
+    };
     auto dma_a = [&](auto r_, int chunk, unsigned stage) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
-        if (a_on[r] && chunk * G::KC + a_q[r] < a.cin_phys)
-            glds16(a_base + chunk * G::KC, a_off[r], lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
+        if constexpr (MULTI) {
+            // ent = this lane's quad of the chunk (entry chunk * 4 + (lane & 3) of the source table), fetched one chunk ahead
+            const unsigned long long pix = (unsigned long long)(pix0 + (wave + 4 * r) * 16 + (lane >> 2));
+            const char* src = reinterpret_cast<const char*>(((unsigned long long)ent.y << 32) | ent.x) + pix * ent.z;
+            if (a_on[r] && ent.w) glds16v(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
+        } else {
+            if (a_on[r] && chunk * G::KC + a_q[r] < a.cin_phys)
+                glds16(a_base + chunk * G::KC, a_off[r], lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
+        }
     };
 
     // clear both input stages once: channel-tail slots are never written, and 0 * stale must not be 0 * NaN
     {
         const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int i = tid; i < 2 * G::A_BYTES / 16; i += G::THREADS) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + 16 * i) = z;
+        if constexpr (MULTI)
+            for (int i = tid; i < 4 * a.n_chunks; i += G::THREADS)
+                *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::LDS_BYTES + 16 * i) = reinterpret_cast<const f32x4*>(a.srctab)[i];
         __syncthreads();
     }
 
@@ -111,8 +142,11 @@ __device__ __forceinline__ void conv_nin_body(const ConvArgs& a, float* smem, lo
 
     const int last = a.n_chunks - 1;
     static_for<0, G::B_ROUNDS>([&](auto r_) DCSCN_INL { dma_b(r_, 0, 0); });
+    load_ent(0);
     static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL { dma_a(r_, 0, 0); });
+    load_ent(last < 1 ? last : 1);
     static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL { dma_a(r_, last < 1 ? last : 1, 1); });
+    load_ent(last < 2 ? last : 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x4 xv[G::MT];
@@ -148,6 +182,7 @@ __device__ __forceinline__ void conv_nin_body(const ConvArgs& a, float* smem, lo
                 if constexpr (s == 3) xn[m] = *(lds_f32x4_ptr)(uintptr_t)(An + m * 16 * G::PSTRIDE);
             });
         });
+        load_ent(chunk + 3 < last ? chunk + 3 : last);      // the next iteration's ca
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         static_for<0, G::MT>([&](auto m_) DCSCN_INL { xv[decltype(m_)::value] = xn[decltype(m_)::value]; });
@@ -192,13 +227,13 @@ __device__ __forceinline__ void conv_nin_body(const ConvArgs& a, float* smem, lo
 }
 
 // grid = (pixel blocks of 256, channel groups)
-template <int NT, int WPS = 3>
+template <int NT, bool MULTI = false, int WPS = 3>
 __global__ __launch_bounds__(256, WPS) void conv_nin(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const long long pix0 = (long long)blockIdx.x * NinGeom<NT>::PIX;
     const int ntile = blockIdx.y;
-    if (ntile < a.n_full) conv_nin_body<NT, NT>(a, smem, pix0, ntile);          // block uniform
-    else if constexpr (NT >= 2) conv_nin_body<NT, NT - 1>(a, smem, pix0, ntile);
+    if (ntile < a.n_full) conv_nin_body<NT, NT, MULTI>(a, smem, pix0, ntile);          // block uniform
+    else if constexpr (NT >= 2) conv_nin_body<NT, NT - 1, MULTI>(a, smem, pix0, ntile);
 }
 
 }  // namespace dcscn

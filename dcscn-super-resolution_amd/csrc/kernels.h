@@ -18,6 +18,12 @@ struct OutDesc {
     int32_t width;    // number of conv output channels stored through this descriptor
 };
 
+struct NinSrcQuad {           // conv_nin multi-source input: one 16-byte channel quad of the virtual concat
+    unsigned long long ptr;   // address of this quad of pixel 0
+    unsigned stride;          // bytes between pixels of the source tensor
+    unsigned valid;           // 0: padding quad past the last channel
+};
+
 // Arguments of the implicit-GEMM convolution (tf.nn.conv2d SAME stride 1 + bias + activator,
 // helper/tf_graph.py:104-153; optional depth_to_space and residual add folded into the store).
 struct ConvArgs {
@@ -51,6 +57,7 @@ struct ConvArgs {
     // conv channel v = phase * 4 + variant.  The epilogue picks the variant of each phase from the pixel's
     // position and stores one value per HR pixel into out0 (stride 1), plus `res`.
     int32_t fold;
+    const void* srctab;       // conv_nin, multi-source input: device array of NinSrcQuad, 4 * n_chunks entries (nullptr: `in` is one tensor)
 };
 
 struct ConvShape {            // kernel variant picked by the plan

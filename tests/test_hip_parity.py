@@ -397,3 +397,21 @@ def test_forward_device_alternating_shapes_and_streams(oracle):
             assert eng.stream() != 0
     finally:
         hip.close()
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_dense_feature_buffers_are_bit_identical_to_the_concat_tensor(oracle, name):
+    """dense_features (default 1): one dense buffer per feature layer and a multi-source NIN GEMM instead of one wide
+    concat tensor.  The virtual channel order, the chunking and every accumulation order are the same, so the
+    output must be the same BITS -- and the pass must really be taken where it applies (kernel list)."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS[name])
+    weights = oracle.synthetic_weights(cfg, seed=3)
+    x, x2 = synthetic_batch(3, 40, 36, cfg["scale"], seed=4)
+    outs = []
+    for dense in (1, 0):
+        with engine.Engine(cfg, device=0) as eng:
+            eng.set_option("dense_features", dense)
+            eng.load_weights(weights)
+            outs.append(eng.forward(x, x2))
+    assert outs[0].tobytes() == outs[1].tobytes()
