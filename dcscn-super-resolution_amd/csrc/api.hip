@@ -46,7 +46,7 @@ inline int pad4(int c) { return (c + 3) & ~3; }
 inline int pad16(int c) { return (c + 15) & ~15; }
 
 enum { EXT_X = -1, EXT_X2 = -2, EXT_Y = -3 };
-enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2, OP_COUT1 = 3 };
+enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2, OP_COUT1 = 3, OP_STREAM = 4 };
 
 struct TensorSpec {
     std::string name;
@@ -113,6 +113,10 @@ struct Op {
     std::vector<std::pair<int, int>> multi;   // (buffer, physical channels = pad4)
     std::vector<NinSrcQuad> h_srctab;         // host copy of the quad table, refilled whenever the arena is re-carved
     NinSrcQuad* d_srctab = nullptr;
+    // OP_STREAM (stream_features): the launches this op replaces, kept for their tensor indices, and the kernel plan
+    std::vector<Op> fused;
+    StreamArgs stream{};
+    int halo = -1;                            // >= 0: receptive-field radius of the op in ITS pixels (else ks / 2)
 };
 
 }  // namespace
@@ -165,6 +169,7 @@ struct dcscn_ctx {
     bool has_last = false;
     bool profile = false;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
+    bool stream_features = true;             // separable narrow nets: CNN1 .. B2 as one row-streamed launch (fuse_feat_stream)
     bool dense_features = true;              // per-layer feature buffers + multi-source NIN GEMM instead of one concat tensor (densify_features)
     int concat_buf = -1;                     // build_graph: the skip-concat buffer, its slices (offset, logical width)
     std::vector<std::pair<int, int>> concat_slices;
@@ -714,7 +719,10 @@ int upload(dcscn_ctx* h, const void* host, size_t bytes, void** dev) {
     return DCSCN_OK;
 }
 
+int pack_feat_stream(dcscn_ctx* h, Op& op);
+
 int finalize_op(dcscn_ctx* h, Op& op) {
+    if (op.kind == OP_STREAM) return pack_feat_stream(h, op);
     if (op.kind == OP_DW) {
         const TensorSpec& w = h->tensors[op.dw_w];          // [k, k, cin, 1] -> [taps][cin]
         int rc = upload(h, w.data.data(), w.data.size() * sizeof(float), (void**)&op.d_w);
@@ -1017,6 +1025,28 @@ inline float* buf_ptr(dcscn_ctx* h, int id) { return reinterpret_cast<float*>(st
 int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, const float* x2, float* y,
               hipStream_t stream) {
     const int Hr = H * op.res, Wr = W * op.res;
+    if (op.kind == OP_STREAM) {
+        StreamArgs a = op.stream;
+        a.x = x;
+        a.out = buf_ptr(h, op.out_buf[0]);
+        a.out_stride = h->bufs[op.out_buf[0]].stride;
+        a.blob = op.d_w;
+        a.N = nb; a.H = H; a.W = W;
+        a.halo = a.L + 1;
+        // column strips of 48 computed pixels; row blocks only where whole images do not fill the chip
+        if (W <= kStreamPX) { a.n_strips = 1; a.useful_w = W; }
+        else { a.useful_w = kStreamPX - 2 * a.halo; a.n_strips = (W + a.useful_w - 1) / a.useful_w; }
+        const int64_t cols = (int64_t)nb * a.n_strips;
+        const int want = (int)std::max<int64_t>(1, (512 + cols - 1) / cols);
+        a.useful_h = std::max(32, (H + want - 1) / want);
+        a.n_blocks = (H + a.useful_h - 1) / a.useful_h;
+        a.rows_c = a.n_blocks == 1 ? H : a.useful_h + 2 * a.halo;
+        a.n_jobs = (int)(cols * a.n_blocks);
+        a.jobs_per_wg = (a.n_jobs + 255) / 256;
+        const int grid = (a.n_jobs + a.jobs_per_wg - 1) / a.jobs_per_wg;
+        HIP_TRY(h, stream_launch(a, grid, stream));
+        return DCSCN_OK;
+    }
     if (op.kind == OP_DW) {
         DwArgs a{};
         a.in = op.in_buf == EXT_X ? x : buf_ptr(h, op.in_buf);
@@ -1109,7 +1139,7 @@ int halo_lr_pixels(const dcscn_ctx* h) {
     double r = 0.0;
     for (const Op& op : h->ops) {
         const int k = op.kind == OP_CONV && op.dwk ? op.dwk : op.ks;
-        r += (double)(k / 2) / op.res;
+        r += (double)(op.halo >= 0 ? op.halo : k / 2) / op.res;
     }
     return (int)std::ceil(r - 1e-9);
 }
@@ -1454,6 +1484,198 @@ int dcscn_set_tensor(dcscn_handle h, const char* name, const float* data, const 
     return DCSCN_OK;
 }
 
+namespace {
+// ---- row-streamed feature extractor (feat_stream.hpp) ---------------------------------------------------
+// The separable narrow nets (depthwise_separable, <= 7 feature layers of <= 32 filters, NIN of <= 32 channels): the
+// launches CNN1/depthwise, CNN1 .. CNNL, B1+A1, B2 become ONE launch that keeps every intermediate tensor in LDS.
+void fuse_feat_stream(dcscn_ctx* h) {
+    const dcscn_config& c = h->cfg;
+    const int L = c.layers;
+    if (!h->stream_features || !c.depthwise_separable || c.cnn_size != 3 || !c.use_nin || L < 2 || L > kStreamMaxL) return;
+    if (c.nin_filters2 > 16 || pad4(c.nin_filters) + pad4(c.nin_filters2) > 32) return;
+    for (int i = 0; i < L; ++i)
+        if (h->sched[i] > 32) return;
+    // expected launch sequence
+    const size_t n_rep = (size_t)L + 3;
+    if (h->ops.size() < n_rep) return;
+    auto is_ds3 = [](const Op& o) { return o.kind == OP_CONV && o.dwk == 3 && o.ks == 1 && o.segs.size() == 1 && o.act == ACT_ALPHA && o.ps == 1 && o.res == 1; };
+    const Op& dw1 = h->ops[0];
+    const Op& c1 = h->ops[1];
+    if (dw1.kind != OP_DW || dw1.ks != 3 || dw1.in_buf != EXT_X || c1.kind != OP_CONV || c1.ks != 1 || c1.cin != 1 || c1.act != ACT_ALPHA || c1.segs.size() != 1) return;
+    for (int i = 1; i < L; ++i)
+        if (!is_ds3(h->ops[1 + i]) || h->ops[1 + i].cout != h->sched[i]) return;
+    const Op& nin = h->ops[L + 1];
+    const Op& b2 = h->ops[L + 2];
+    if (nin.kind != OP_CONV || nin.ks != 1 || nin.dwk != 0 || nin.segs.size() != 2 || nin.act != ACT_ALPHA || !is_ds3(b2)) return;
+    if (b2.out_buf[0] != nin.out_buf[1] || b2.out_off[0] != 0 || nin.out_off[1] != pad4(c.nin_filters2)) return;
+
+    // LDS budget: rings + the filters that are indexed by a run-time layer (A1 || B1 slices, depthwise)
+    auto units = [](int ch) { const int q = pad4(ch) / 4; return q | 1; };
+    size_t lds = 0;
+    for (int i = 0; i < L; ++i) lds += (size_t)3 * kStreamRowPx * units(h->sched[i]) * 16;
+    lds += (size_t)3 * kStreamRowPx * units(c.nin_filters2) * 16;
+    for (int i = 0; i < L; ++i) lds += (size_t)((h->sched[i] + 15) / 16) * 2 * 64 * 16;
+    for (int i = 0; i + 1 < L; ++i) lds += (size_t)9 * (pad4(h->sched[i]) / 4) * 16;
+    lds += (size_t)9 * (pad4(c.nin_filters2) / 4) * 16;
+    if (lds > 160 * 1024) return;
+
+    Op f;
+    f.kind = OP_STREAM;
+    f.name = "CNN1.." + b2.name + " (streamed)";
+    f.ks = 3;
+    f.cin = 1;
+    f.cout = c.nin_filters + c.nin_filters2;
+    f.res = 1;
+    f.act = ACT_ALPHA;
+    f.in_buf = EXT_X;
+    f.out_buf[0] = f.out_buf[1] = b2.out_buf[0];
+    f.out_width[0] = h->bufs[b2.out_buf[0]].stride;
+    f.halo = L + 1;
+    for (size_t i = 0; i < n_rep; ++i) {
+        f.macs += h->ops[i].macs;
+        f.fused.push_back(h->ops[i]);
+    }
+    f.bytes = 4 + 4 * (int64_t)h->bufs[b2.out_buf[0]].stride;
+    const int t1 = nin.out_buf[0], cat = h->concat_buf;
+    h->ops.erase(h->ops.begin(), h->ops.begin() + n_rep);
+    h->ops.insert(h->ops.begin(), f);
+    for (int dead : {t1, cat, dw1.out_buf[0]}) {
+        bool used = false;
+        for (const Op& o : h->ops) used = used || o.in_buf == dead || o.out_buf[0] == dead || o.out_buf[1] == dead;
+        if (!used && dead >= 0) h->bufs[dead].stride = 0;
+    }
+    h->concat_buf = -1;                                    // nothing left for densify_features
+}
+
+int pack_feat_stream(dcscn_ctx* h, Op& op) {
+    const dcscn_config& c = h->cfg;
+    const int L = c.layers, nb = c.nin_filters2, na = c.nin_filters;
+    StreamArgs& a = op.stream;
+    a = StreamArgs{};
+    a.L = L;
+    a.n_conv = L;                      // CNN2 .. CNNL and B2
+    a.total_lag = 2 * L + 1;
+    a.nb_quads = pad4(nb) / 4;
+    auto ring = [&](int ch, int* off) {
+        StreamRing r;
+        r.quads = pad4(ch) / 4;
+        r.units = r.quads | 1;
+        r.off = *off;
+        *off += 3 * kStreamRowPx * r.units * 16;
+        return r;
+    };
+    int lds = 0;
+    std::vector<StreamRing> fr(L);
+    for (int i = 0; i < L; ++i) fr[i] = ring(h->sched[i], &lds);
+    a.b1 = ring(nb, &lds);
+    a.first_out = fr[0];
+    a.ring_bytes = lds;
+
+    std::vector<float> blob;
+    auto tens = [&](int id) -> const std::vector<float>& { return h->tensors[id].data; };
+    // --- LDS image: A1 || B1 slices, then the depthwise filters ---
+    const Op& nin = op.fused[L + 1];
+    const ColSeg& sb = nin.segs[0];
+    const ColSeg& sa = nin.segs[1];
+    int cbase = 0;
+    for (int i = 0; i < L; ++i) {
+        const int C = h->sched[i];
+        StreamNinSrc& s = a.nin[i];
+        s.ring = fr[i];
+        s.chunks = (C + 15) / 16;
+        const int rem = C - 16 * (s.chunks - 1);
+        s.last_steps = rem >= 4 ? 4 : rem;
+        s.w = lds;
+        const size_t base = blob.size();
+        blob.resize(base + (size_t)s.chunks * 2 * 64 * 4, 0.0f);
+        for (int ch = 0; ch < s.chunks; ++ch)
+            for (int n = 0; n < 2; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int k = 0; k < 4; ++k) {
+                        const int ci = 16 * ch + 4 * (lane >> 4) + k, v = 16 * n + (lane & 15);
+                        if (ci >= C) continue;
+                        const ColSeg* sg = nullptr;
+                        int co = 0;
+                        if (v < pad4(nb)) { if (v < nb) { sg = &sb; co = v; } }
+                        else if (v - pad4(nb) < na) { sg = &sa; co = v - pad4(nb); }
+                        if (!sg) continue;
+                        const int cols = (int)h->tensors[sg->w].shape.back();
+                        float w = tens(sg->w)[(size_t)(cbase + ci) * cols + sg->col0 + co];
+                        if (sg->dw1 >= 0) w = tens(sg->dw1)[cbase + ci] * w;      // folded 1x1 depthwise half, as finalize_op
+                        blob[base + ((size_t)(ch * 2 + n) * 64 + lane) * 4 + k] = w;
+                    }
+        lds += s.chunks * 2 * 64 * 16;
+        cbase += C;
+    }
+    for (int i = 0; i < L; ++i) {                      // conv i: CNN(i+2) for i < L-1, B2 for i == L-1
+        const bool is_b2 = i == L - 1;
+        const Op& src = is_b2 ? op.fused[L + 2] : op.fused[2 + i];
+        const int cin = is_b2 ? nb : h->sched[i];
+        StreamConv& cv = a.conv[i];
+        cv.in = is_b2 ? a.b1 : fr[i];
+        cv.lag = is_b2 ? 2 * L + 1 : 2 * (i + 1);
+        cv.to_global = is_b2 ? 1 : 0;
+        if (is_b2) { cv.out = StreamRing{-1, 0, pad4(nb) / 4}; }
+        else cv.out = fr[i + 1];
+        cv.dww = lds;
+        const size_t base = blob.size();
+        const int quads = pad4(cin) / 4;
+        blob.resize(base + (size_t)9 * quads * 4, 0.0f);
+        const std::vector<float>& dw = tens(src.dw_w);          // [3, 3, cin, 1]
+        for (int k = 0; k < 9; ++k)
+            for (int ci = 0; ci < cin; ++ci) blob[base + (size_t)k * quads * 4 + ci] = dw[(size_t)k * cin + ci];
+        lds += 9 * quads * 16;
+    }
+    a.ldsw_src = 0;
+    a.ldsw_bytes = lds - a.ring_bytes;
+    if ((size_t)a.ldsw_bytes != blob.size() * sizeof(float)) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat_stream LDS image size");
+
+    auto bias_alpha = [&](const Op& o, const ColSeg& sg, int dst, int base) {
+        for (int co = 0; co < sg.cout; ++co) {
+            blob[base + dst + co] = sg.b >= 0 ? tens(sg.b)[sg.col0 + co] : 0.0f;
+            blob[base + 32 + dst + co] = sg.alpha >= 0 ? tens(sg.alpha)[sg.col0 + co] : o.const_alpha;
+        }
+    };
+    // --- CNN1: depthwise[9] (+3 pad), pointwise[32], bias[32], slope[32] ---
+    {
+        const Op& dw1 = op.fused[0];
+        const Op& c1 = op.fused[1];
+        a.first_w = (int)blob.size();
+        blob.resize(blob.size() + 12 + 96, 0.0f);
+        for (int k = 0; k < 9; ++k) blob[a.first_w + k] = tens(dw1.dw_w)[k];
+        const ColSeg& sg = c1.segs[0];
+        for (int co = 0; co < sg.cout; ++co) blob[a.first_w + 12 + co] = tens(sg.w)[co];      // [1, 1, 1, C1]
+        bias_alpha(c1, sg, 0, a.first_w + 44);
+    }
+    // --- pointwise filters, bias, slope of the streamed convs ---
+    for (int i = 0; i < L; ++i) {
+        const bool is_b2 = i == L - 1;
+        const Op& src = is_b2 ? op.fused[L + 2] : op.fused[2 + i];
+        const ColSeg& sg = src.segs[0];
+        const int cin = is_b2 ? nb : h->sched[i], cout = sg.cout;
+        StreamConv& cv = a.conv[i];
+        cv.wp = (int)blob.size();
+        blob.resize(blob.size() + 2 * 4 * 2 * 64, 0.0f);
+        const std::vector<float>& pw = tens(sg.w);              // [1, 1, cin, cout]
+        for (int ch = 0; ch < 2; ++ch)
+            for (int st = 0; st < 4; ++st)
+                for (int n = 0; n < 2; ++n)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int ci = 16 * ch + 4 * (lane >> 4) + st, co = 16 * n + (lane & 15);
+                        if (ci < cin && co < cout) blob[cv.wp + ((ch * 4 + st) * 2 + n) * 64 + lane] = pw[(size_t)ci * cout + co];
+                    }
+        cv.ba = (int)blob.size();
+        blob.resize(blob.size() + 64, 0.0f);
+        bias_alpha(src, sg, 0, cv.ba);
+    }
+    a.nin_ba = (int)blob.size();
+    blob.resize(blob.size() + 64, 0.0f);
+    bias_alpha(nin, sb, 0, a.nin_ba);
+    bias_alpha(nin, sa, pad4(nb), a.nin_ba);
+    return upload(h, blob.data(), blob.size() * sizeof(float), (void**)&op.d_w);
+}
+}  // namespace
+
 // ---- dense per-layer feature buffers ------------------------------------------------------------------
 // build_graph lets every feature layer store into its slice of ONE [n, H, W, sum pad4(C_i)] tensor, which makes tf.concat
 // free -- but a narrow slice of a wide NHWC record is a partial, misaligned cache-line access per pixel, for the layer that
@@ -1504,6 +1726,7 @@ int dcscn_finalize(dcscn_handle h) {
         if (!t.set) return fail(h, DCSCN_ERR_MISSING_TENSOR, "variable '%s' was never set", t.name.c_str());
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->fold_tail) fold_linear_tail(h);      // silently keeps the layer-by-layer graph where it does not apply
+    fuse_feat_stream(h);
     densify_features(h);
     for (Op& op : h->ops) {
         int rc = finalize_op(h, op);
@@ -1536,7 +1759,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     const Op& op = h->ops[index];
     memset(out, 0, sizeof *out);
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
-    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : "depthwise");
+    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
     out->out_channels = op.cout;
@@ -1584,6 +1807,11 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "fold_linear_tail")) {
         if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the fold_linear_tail option must be set before dcscn_finalize");
         h->fold_tail = value != 0;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "stream_features")) {
+        if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the stream_features option must be set before dcscn_finalize");
+        h->stream_features = value != 0;
         return DCSCN_OK;
     }
     if (!strcmp(key, "dense_features")) {

@@ -1,0 +1,17 @@
+// Launcher of the row-streamed feature extractor (feat_stream.hpp).
+#include "feat_stream.hpp"
+
+namespace dcscn {
+
+void stream_init_kernels() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&feat_stream), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t stream_launch(const StreamArgs& a, int grid, hipStream_t stream) {
+    const int threads = (1 + a.n_conv + a.L) * 64;
+    const size_t lds = (size_t)a.ring_bytes + a.ldsw_bytes;
+    hipLaunchKernelGGL(feat_stream, dim3(grid), dim3(threads), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace dcscn

@@ -94,6 +94,56 @@ constexpr int kNinKC = 16;
 constexpr int kNinMaxNT = 6;
 hipError_t nin_init_kernels();
 hipError_t nin_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
+
+// ---- row-streamed feature extractor of the separable narrow nets (feat_stream.hpp) ----
+constexpr int kStreamPX = 48;                  // computed columns per strip: three 16-pixel MFMA tiles
+constexpr int kStreamRowPx = kStreamPX + 2;    // + one zero column on each side
+constexpr int kStreamMaxL = 7;                 // feature layers (2L + 1 waves <= 16)
+constexpr int kStreamMT = kStreamPX / 16;
+
+struct StreamRing {
+    int32_t off;      // LDS byte offset of [3 slots][kStreamRowPx][units] float4
+    int32_t units;    // 16-byte units per pixel (odd)
+    int32_t quads;    // units that hold channels: pad4(C) / 4
+};
+struct StreamConv {   // separable 3x3 layer of the stream
+    StreamRing in, out;
+    int32_t lag;          // computes stream row t - lag at step t
+    int32_t dww;          // LDS byte offset of the depthwise filter [9][in.quads] float4
+    int32_t wp;           // blob float offset of the pointwise filter [2 chunks][4 k-steps][2 tiles][64 lanes]
+    int32_t ba;           // blob float offset of bias[32], slope[32]
+    int32_t to_global;    // 1: the layer stores to `out` channels [0, 4 * out.quads) instead of a ring (B2)
+    int32_t pad_;
+};
+struct StreamNinSrc {     // one feature layer as a K-slice of A1 || B1
+    StreamRing ring;
+    int32_t chunks;       // 16-channel chunks
+    int32_t w;            // LDS byte offset of [chunk][2 tiles][64 lanes] float4 (k-steps 0..3)
+    int32_t last_steps;   // k-steps of the last chunk that hold channels (1..4)
+};
+struct StreamArgs {
+    const float* x;       // [N, H, W] luma
+    float* out;           // Concat2 [N, H, W, out_stride]: B2 at channel 0, A1 at channel 4 * nb_quads
+    const float* blob;    // packed parameters (api.hip: pack_feat_stream)
+    int32_t out_stride;
+    int32_t N, H, W;
+    int32_t n_strips, useful_w, halo;      // strip s computes columns [s * useful_w - halo, .. + 48), stores [s * useful_w, (s + 1) * useful_w)
+    int32_t n_blocks, useful_h, rows_c;    // row block b computes rows_c rows from b * useful_h - halo (0 when n_blocks == 1)
+    int32_t n_jobs, jobs_per_wg;
+    int32_t L, n_conv, total_lag;
+    int32_t ring_bytes, ldsw_bytes, ldsw_src;   // LDS image: [0, ring_bytes) zero, then ldsw_bytes copied from blob + ldsw_src
+    int32_t first_w;                       // blob offset of CNN1: depthwise[9 (+3)], pointwise[32], bias[32], slope[32]
+    StreamRing first_out;
+    StreamConv conv[kStreamMaxL];          // CNN2 .. CNNL, B2
+    StreamNinSrc nin[kStreamMaxL];
+    StreamRing b1;
+    int32_t nin_ba;                        // blob offset of bias[32], slope[32] of [B1 | A1]
+    int32_t nb_quads;                      // channel quads of the B1 part
+};
+
+void stream_init_kernels();
+hipError_t stream_launch(const StreamArgs& a, int grid, hipStream_t stream);
+
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
 int conv_max_fused_dw_nt();
 

@@ -27,7 +27,9 @@ hipError_t conv_init_kernels() {
     if (e == hipSuccess) e = conv_init_k5();
     if (e == hipSuccess) e = conv_init_k7();
     if (e == hipSuccess) e = wino_init_kernels();
-    return e != hipSuccess ? e : nin_init_kernels();
+    if (e == hipSuccess) e = nin_init_kernels();
+    if (e == hipSuccess) stream_init_kernels();
+    return e;
 }
 
 hipError_t conv_launch(const ConvShape& s, const ConvArgs& a, int n_tiles, hipStream_t stream) {
