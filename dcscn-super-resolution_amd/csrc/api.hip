@@ -1513,10 +1513,15 @@ void fuse_feat_stream(dcscn_ctx* h) {
     auto units = [](int ch) { const int q = pad4(ch) / 4; return q | 1; };
     size_t lds = 0;
     for (int i = 0; i < L; ++i) lds += (size_t)3 * kStreamRowPx * units(h->sched[i]) * 16;
-    lds += (size_t)3 * kStreamRowPx * units(c.nin_filters2) * 16;
+    lds += (size_t)4 * kStreamRowPx * units(c.nin_filters2) * 16;
     for (int i = 0; i < L; ++i) lds += (size_t)((h->sched[i] + 15) / 16) * 2 * 64 * 16;
     for (int i = 0; i + 1 < L; ++i) lds += (size_t)9 * (pad4(h->sched[i]) / 4) * 16;
     lds += (size_t)9 * (pad4(c.nin_filters2) / 4) * 16;
+    for (int i = 0; i < L; ++i) {                     // pointwise filters [chunk][tile][64] float4, bias + slope
+        const int cin = i == L - 1 ? c.nin_filters2 : h->sched[i], cout = i == L - 1 ? c.nin_filters2 : h->sched[i + 1];
+        lds += (size_t)((cin + 15) / 16) * ((cout + 15) / 16) * 64 * 16 + 256;
+    }
+    lds += 256;
     if (lds > 160 * 1024) return;
 
     Op f;
@@ -1556,18 +1561,19 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
     a.n_conv = L;                      // CNN2 .. CNNL and B2
     a.total_lag = 2 * L + 1;
     a.nb_quads = pad4(nb) / 4;
-    auto ring = [&](int ch, int* off) {
+    auto ring = [&](int ch, int slots, int* off) {
         StreamRing r;
         r.quads = pad4(ch) / 4;
         r.units = r.quads | 1;
+        r.slots = slots;
         r.off = *off;
-        *off += 3 * kStreamRowPx * r.units * 16;
+        *off += slots * kStreamRowPx * r.units * 16;
         return r;
     };
     int lds = 0;
     std::vector<StreamRing> fr(L);
-    for (int i = 0; i < L; ++i) fr[i] = ring(h->sched[i], &lds);
-    a.b1 = ring(nb, &lds);
+    for (int i = 0; i < L; ++i) fr[i] = ring(h->sched[i], 3, &lds);
+    a.b1 = ring(nb, 4, &lds);
     a.first_out = fr[0];
     a.ring_bytes = lds;
 
@@ -1615,7 +1621,7 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
         cv.in = is_b2 ? a.b1 : fr[i];
         cv.lag = is_b2 ? 2 * L + 1 : 2 * (i + 1);
         cv.to_global = is_b2 ? 1 : 0;
-        if (is_b2) { cv.out = StreamRing{-1, 0, pad4(nb) / 4}; }
+        if (is_b2) { cv.out = StreamRing{-1, 0, pad4(nb) / 4, 0}; }
         else cv.out = fr[i + 1];
         cv.dww = lds;
         const size_t base = blob.size();
@@ -1626,17 +1632,52 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
             for (int ci = 0; ci < cin; ++ci) blob[base + (size_t)k * quads * 4 + ci] = dw[(size_t)k * cin + ci];
         lds += 9 * quads * 16;
     }
-    a.ldsw_src = 0;
-    a.ldsw_bytes = lds - a.ring_bytes;
-    if ((size_t)a.ldsw_bytes != blob.size() * sizeof(float)) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat_stream LDS image size");
-
-    auto bias_alpha = [&](const Op& o, const ColSeg& sg, int dst, int base) {
+    auto bias_alpha = [&](const Op& o, const ColSeg& sg, int dst, size_t base) {
         for (int co = 0; co < sg.cout; ++co) {
             blob[base + dst + co] = sg.b >= 0 ? tens(sg.b)[sg.col0 + co] : 0.0f;
             blob[base + 32 + dst + co] = sg.alpha >= 0 ? tens(sg.alpha)[sg.col0 + co] : o.const_alpha;
         }
     };
-    // --- CNN1: depthwise[9] (+3 pad), pointwise[32], bias[32], slope[32] ---
+    // --- pointwise filters [chunk][tile][lane] float4, bias, slope of the streamed convs ---
+    for (int i = 0; i < L; ++i) {
+        const bool is_b2 = i == L - 1;
+        const Op& src = is_b2 ? op.fused[L + 2] : op.fused[2 + i];
+        const ColSeg& sg = src.segs[0];
+        const int cin = is_b2 ? nb : h->sched[i], cout = sg.cout;
+        const int chunks = (cin + 15) / 16, tiles = (cout + 15) / 16;
+        StreamConv& cv = a.conv[i];
+        cv.wp = lds;
+        size_t base = blob.size();
+        blob.resize(base + (size_t)chunks * tiles * 64 * 4, 0.0f);
+        const std::vector<float>& pw = tens(sg.w);              // [1, 1, cin, cout]
+        for (int ch = 0; ch < chunks; ++ch)
+            for (int n = 0; n < tiles; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int st = 0; st < 4; ++st) {
+                        const int ci = 16 * ch + 4 * (lane >> 4) + st, co = 16 * n + (lane & 15);
+                        if (ci < cin && co < cout) blob[base + ((size_t)(ch * tiles + n) * 64 + lane) * 4 + st] = pw[(size_t)ci * cout + co];
+                    }
+        lds += chunks * tiles * 64 * 16;
+        cv.ba = lds;
+        base = blob.size();
+        blob.resize(base + 64, 0.0f);
+        bias_alpha(src, sg, 0, base);
+        lds += 256;
+    }
+    {
+        a.nin_ba = lds;
+        const size_t base = blob.size();
+        blob.resize(base + 64, 0.0f);
+        bias_alpha(nin, sb, 0, base);
+        bias_alpha(nin, sa, pad4(nb), base);
+        lds += 256;
+    }
+    a.ldsw_src = 0;
+    a.ldsw_bytes = lds - a.ring_bytes;
+    if ((size_t)a.ldsw_bytes != blob.size() * sizeof(float)) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat_stream LDS image size");
+    if (lds > 160 * 1024) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat_stream needs %d bytes of LDS", lds);
+
+    // --- CNN1 (global, read once into registers): depthwise[9] (+3 pad), pointwise[32], bias[32], slope[32] ---
     {
         const Op& dw1 = op.fused[0];
         const Op& c1 = op.fused[1];
@@ -1645,33 +1686,8 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
         for (int k = 0; k < 9; ++k) blob[a.first_w + k] = tens(dw1.dw_w)[k];
         const ColSeg& sg = c1.segs[0];
         for (int co = 0; co < sg.cout; ++co) blob[a.first_w + 12 + co] = tens(sg.w)[co];      // [1, 1, 1, C1]
-        bias_alpha(c1, sg, 0, a.first_w + 44);
+        bias_alpha(c1, sg, 0, (size_t)a.first_w + 44);
     }
-    // --- pointwise filters, bias, slope of the streamed convs ---
-    for (int i = 0; i < L; ++i) {
-        const bool is_b2 = i == L - 1;
-        const Op& src = is_b2 ? op.fused[L + 2] : op.fused[2 + i];
-        const ColSeg& sg = src.segs[0];
-        const int cin = is_b2 ? nb : h->sched[i], cout = sg.cout;
-        StreamConv& cv = a.conv[i];
-        cv.wp = (int)blob.size();
-        blob.resize(blob.size() + 2 * 4 * 2 * 64, 0.0f);
-        const std::vector<float>& pw = tens(sg.w);              // [1, 1, cin, cout]
-        for (int ch = 0; ch < 2; ++ch)
-            for (int st = 0; st < 4; ++st)
-                for (int n = 0; n < 2; ++n)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int ci = 16 * ch + 4 * (lane >> 4) + st, co = 16 * n + (lane & 15);
-                        if (ci < cin && co < cout) blob[cv.wp + ((ch * 4 + st) * 2 + n) * 64 + lane] = pw[(size_t)ci * cout + co];
-                    }
-        cv.ba = (int)blob.size();
-        blob.resize(blob.size() + 64, 0.0f);
-        bias_alpha(src, sg, 0, cv.ba);
-    }
-    a.nin_ba = (int)blob.size();
-    blob.resize(blob.size() + 64, 0.0f);
-    bias_alpha(nin, sb, 0, a.nin_ba);
-    bias_alpha(nin, sa, pad4(nb), a.nin_ba);
     return upload(h, blob.data(), blob.size() * sizeof(float), (void**)&op.d_w);
 }
 }  // namespace

@@ -22,8 +22,10 @@
 // receptive field (L+1) and only their interior is stored.
 //
 // MFMA operand layout (v_mfma_f32_16x16x4_f32, A = filters, B = 16 pixels): lane (j = lane & 15, q = lane >> 4) reads ONE
-// ds_read_b128 = channels 4q' .. 4q'+3 (q' = 4 * chunk + q) of pixel j and uses its four floats as the B operand of four
+// ds_read_b128 = channels 4q' .. 4q'+3 (q' = 4 * chunk + q) of a pixel and uses its four floats as the B operand of four
 // k-steps; k-step s of a chunk therefore covers channels {16 chunk + 4q + s}, and the filters are packed to match.
+// Column j of pixel tile m is pixel 3j + m, not 16m + j: a lane's three pixels are neighbours, so the 3x3 depthwise
+// window of all three needs 5 reads per row instead of 9 (LDS bandwidth is the second limiter after the MFMA pipe).
 // Ring rows are [pixel -1 .. 48][units] float4 with an ODD number of units per pixel: the 16 lanes of a ds_read_b128
 // phase hit 16 different 16-byte bank groups.
 #pragma once
@@ -35,7 +37,15 @@ typedef const __attribute__((address_space(3))) f32x4* stream_lds_rd;
 typedef __attribute__((address_space(3))) f32x4* stream_lds_wr;
 
 __device__ __forceinline__ void stream_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ f32x4 stream_ld(unsigned addr) { return *(stream_lds_rd)(uintptr_t)addr; }
+__device__ __forceinline__ void stream_st(unsigned addr, f32x4 v) { *(stream_lds_wr)(uintptr_t)addr = v; }
 
+// Decodes stream rows (all values are wave uniform).  A job = (image, row block, column strip); its rows are followed
+// by one separator row.  Rows are visited in increasing order, so the divisions run once per job.
+struct StreamCursor {
+    int base = 1 << 30;   // stream index of the cached job's first row
+    int img = 0, yb = 0, y0 = 0, y1 = 0, sx = 0, ux0 = 0, ux1 = 0;
+};
 struct StreamRow {
     int img, r;           // image, image row (may lie outside [0, H): zero row)
     int sx;               // image column of computed column 0
@@ -44,23 +54,33 @@ struct StreamRow {
     bool store;           // row belongs to the block's interior
 };
 
-__device__ __forceinline__ StreamRow stream_row(const StreamArgs& a, int j0, int g) {
-    StreamRow o;
+__device__ __forceinline__ StreamRow stream_row(const StreamArgs& a, int j0, StreamCursor& c, int g) {
     const int per = a.rows_c + 1;
-    const int job = j0 + g / per, i = g % per;
-    const int per_img = a.n_strips * a.n_blocks;
-    o.img = job / per_img;
-    const int rem = job % per_img;
-    const int blk = rem / a.n_strips, strip = rem % a.n_strips;
-    const int yb = a.n_blocks == 1 ? 0 : blk * a.useful_h - a.halo;
-    o.r = yb + i;
+    if (g < c.base || g >= c.base + per) {
+        const int jl = g / per;
+        c.base = jl * per;
+        const int job = j0 + jl;
+        const int per_img = a.n_strips * a.n_blocks;
+        c.img = job / per_img;
+        const int rem = job - c.img * per_img;
+        const int blk = rem / a.n_strips, strip = rem - blk * a.n_strips;
+        const bool one_b = a.n_blocks == 1, one_s = a.n_strips == 1;
+        c.yb = one_b ? 0 : blk * a.useful_h - a.halo;
+        c.y0 = one_b ? 0 : blk * a.useful_h;
+        c.y1 = one_b ? a.H : min(a.H, c.y0 + a.useful_h);
+        c.sx = one_s ? 0 : strip * a.useful_w - a.halo;
+        c.ux0 = one_s ? 0 : strip * a.useful_w;
+        c.ux1 = one_s ? a.W : min(a.W, c.ux0 + a.useful_w);
+    }
+    StreamRow o;
+    const int i = g - c.base;
+    o.img = c.img;
+    o.r = c.yb + i;
     o.zero = i == a.rows_c || o.r < 0 || o.r >= a.H;
-    const int y0 = a.n_blocks == 1 ? 0 : blk * a.useful_h;
-    const int y1 = a.n_blocks == 1 ? a.H : min(a.H, y0 + a.useful_h);
-    o.store = !o.zero && o.r >= y0 && o.r < y1;
-    o.sx = a.n_strips == 1 ? 0 : strip * a.useful_w - a.halo;
-    o.ux0 = a.n_strips == 1 ? 0 : strip * a.useful_w;
-    o.ux1 = a.n_strips == 1 ? a.W : min(a.W, o.ux0 + a.useful_w);
+    o.store = !o.zero && o.r >= c.y0 && o.r < c.y1;
+    o.sx = c.sx;
+    o.ux0 = c.ux0;
+    o.ux1 = c.ux1;
     return o;
 }
 
@@ -72,6 +92,8 @@ __device__ __forceinline__ f32x4 stream_prelu(f32x4 v, f32x4 b, f32x4 al) {
     v.w = v.w > 0.0f ? v.w : al.w * v.w;
     return v;
 }
+
+constexpr f32x4 kStreamZero = {0.0f, 0.0f, 0.0f, 0.0f};
 
 // ---- CNN1: Y -> depthwise 3x3 (one channel) -> pointwise 1 -> C1, bias, PReLU ------------------------------------
 __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned lds0, int j0, int rows, int T, int lane) {
@@ -86,25 +108,23 @@ __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned 
         bs[n] = *reinterpret_cast<const f32x4*>(a.blob + a.first_w + 44 + n * 16 + 4 * q);
         al[n] = *reinterpret_cast<const f32x4*>(a.blob + a.first_w + 76 + n * 16 + 4 * q);
     }
-    // rows g-1, g, g+1 in registers and row g+2 in flight; a zero row IS the SAME padding of its neighbours
-    float xw[4][kStreamMT][3];
-    auto load_row = [&](int gs, float (&dst)[kStreamMT][3]) DCSCN_INL {
+    // rows g-1, g, g+1 in registers and row g+2 in flight; a zero row IS the SAME padding of its neighbours.
+    // A lane holds columns 3j-1 .. 3j+3 of each row: the windows of its pixels 3j, 3j+1, 3j+2.
+    float xw[4][5];
+    StreamCursor lc, cc;
+    auto load_row = [&](int gs, float (&dst)[5]) DCSCN_INL {
         const bool in = gs >= 0 && gs < rows;
-        const StreamRow ri = stream_row(a, j0, in ? gs : 0);
+        const StreamRow ri = stream_row(a, j0, lc, in ? gs : 0);
         const bool live = in && !ri.zero;
         const float* row = a.x + ((size_t)ri.img * a.H + (live ? ri.r : 0)) * a.W;
 #pragma unroll
-        for (int m = 0; m < kStreamMT; ++m)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int cx = ri.sx + 16 * m + j + dx - 1;
-                dst[m][dx] = live && cx >= 0 && cx < a.W ? row[cx] : 0.0f;
-            }
+        for (int k = 0; k < 5; ++k) {
+            const int cx = ri.sx + 3 * j + k - 1;
+            dst[k] = live && cx >= 0 && cx < a.W ? row[cx] : 0.0f;
+        }
     };
 #pragma unroll
-    for (int m = 0; m < kStreamMT; ++m)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) xw[1][m][dx] = 0.0f;
+    for (int k = 0; k < 5; ++k) xw[1][k] = 0.0f;
     load_row(0, xw[2]);
     load_row(1, xw[3]);
     for (int t = 0; t < T; ++t) {
@@ -112,23 +132,21 @@ __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned 
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int m = 0; m < kStreamMT; ++m)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) xw[s][m][dx] = xw[s + 1][m][dx];
+            for (int k = 0; k < 5; ++k) xw[s][k] = xw[s + 1][k];
         load_row(g + 2, xw[3]);
         const bool live = g < rows;
         float d[kStreamMT];
         bool ok[kStreamMT];
         if (live) {
-            const StreamRow ri = stream_row(a, j0, g);
+            const StreamRow ri = stream_row(a, j0, cc, g);
 #pragma unroll
             for (int m = 0; m < kStreamMT; ++m) {
                 d[m] = 0.0f;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) d[m] = fmaf(w9[dy * 3 + dx], xw[dy][m][dx], d[m]);
-                const int cx = ri.sx + 16 * m + j;
+                    for (int dx = 0; dx < 3; ++dx) d[m] = fmaf(w9[dy * 3 + dx], xw[dy][m + dx], d[m]);
+                const int cx = ri.sx + 3 * j + m;
                 ok[m] = !ri.zero && cx >= 0 && cx < a.W;
             }
         }
@@ -141,94 +159,92 @@ __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned 
                 for (int n = 0; n < 2; ++n)
                     if (n * 4 + q < a.first_out.quads) {
                         const f32x4 r = stream_prelu(pw[n] * d[m], bs[n], al[n]);
-                        *(stream_lds_wr)(uintptr_t)(lds0 + a.first_out.off +
-                                                   ((slot * kStreamRowPx + 16 * m + j + 1) * a.first_out.units + n * 4 + q) * 16u) =
-                            ok[m] ? r : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        stream_st(lds0 + a.first_out.off + ((slot * kStreamRowPx + 3 * j + m + 1) * a.first_out.units + n * 4 + q) * 16u,
+                                  ok[m] ? r : kStreamZero);
                     }
         }
         stream_barrier();
     }
 }
 
+// The depthwise 3x3 + pointwise core shared by every separable layer of the streamed kernels: rowb[dy] = LDS address of
+// (row dy, the lane's first window pixel, quad 0); the lane's three pixels are window positions 0..2, 1..3, 2..4.
+// acc[m][n] += sum over chunks / k-steps of pointwise[n] x depthwise(pixel m).
+template <int CH, int NT>
+__device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[kStreamMT][NT], unsigned lds0, const unsigned (&rowb)[3], unsigned in_px,
+                                             int in_quads, int dww, int wpo, int q, int lane) {
+    static_for<0, CH>([&](auto ch_) DCSCN_INL {
+        constexpr int ch = decltype(ch_)::value;
+        const int quad = ch * 4 + q;
+        const bool qv = quad < in_quads;
+        const unsigned qoff = (unsigned)(qv ? quad : 0) * 16u;
+        f32x4 wp[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wp[n] = stream_ld(lds0 + wpo + (unsigned)((ch * NT + n) * 64 + lane) * 16u);
+        f32x4 d[kStreamMT];
+#pragma unroll
+        for (int m = 0; m < kStreamMT; ++m) d[m] = kStreamZero;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            f32x4 dw[3], xv[5];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) dw[dx] = stream_ld(lds0 + dww + (unsigned)((dy * 3 + dx) * in_quads) * 16u + qoff);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) xv[k] = stream_ld(rowb[dy] + (unsigned)k * in_px + qoff);
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) d[m] += dw[dx] * xv[m + dx];
+            asm volatile("" ::: "memory");      // keeps the next row's 8 reads behind these FMAs: 32 VGPRs, not 96
+        }
+        if (!qv) {
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m) d[m] = kStreamZero;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[n][s], d[m][s], acc[m][n], 0, 0, 0);
+    });
+}
+
 // ---- CNN2 .. CNNL, B2: depthwise 3x3 from the predecessor's ring -> pointwise GEMM -> bias, PReLU -----------------
+// CH = 16-channel chunks of the input, NT = 16-channel tiles of the output (compile time: no branches between the MFMAs)
+template <int CH, int NT>
 __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const StreamConv& c, unsigned lds0, int j0, int rows, int T, int lane) {
     const int j = lane & 15, q = lane >> 4;
-    const int in_chunks = (c.in.quads + 3) >> 2;
-    const int out_tiles = (c.out.quads + 3) >> 2;
     const unsigned in_px = (unsigned)c.in.units * 16u, in_row = (unsigned)kStreamRowPx * in_px;
+    StreamCursor cur;
     for (int t = 0; t < T; ++t) {
         const int g = t - c.lag;
         const bool live = g >= 0 && g < rows;
-        f32x4 acc[kStreamMT][2];
+        f32x4 acc[kStreamMT][NT];
 #pragma unroll
         for (int m = 0; m < kStreamMT; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        StreamRow ri{};
+            for (int n = 0; n < NT; ++n) acc[m][n] = kStreamZero;
         if (live) {
-            ri = stream_row(a, j0, g);
+            const StreamRow ri = stream_row(a, j0, cur, g);
             if (!ri.zero) {
                 unsigned rowb[3];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + c.in.off + (unsigned)((g + 2 + dy) % 3) * in_row;   // rows g-1, g, g+1
-                static_for<0, 2>([&](auto ch_) DCSCN_INL {
-                    constexpr int ch = decltype(ch_)::value;
-                    if (ch < in_chunks) {
-                        const int quad = ch * 4 + q;
-                        const bool qv = quad < c.in.quads;
-                        const unsigned qoff = (unsigned)(qv ? quad : 0) * 16u;
-                        // pointwise filter of the chunk: 2 KB per wave and step from L1 / L2 (resident it costs 16 VGPRs too many)
-                        float wp[4][2];
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-#pragma unroll
-                            for (int n = 0; n < 2; ++n) wp[s][n] = a.blob[c.wp + ((ch * 4 + s) * 2 + n) * 64 + lane];
-                        f32x4 dw[9];
-#pragma unroll
-                        for (int k = 0; k < 9; ++k)
-                            dw[k] = *(stream_lds_rd)(uintptr_t)(lds0 + c.dww + (unsigned)(k * c.in.quads) * 16u + qoff);
-                        static_for<0, kStreamMT>([&](auto m_) DCSCN_INL {
-                            constexpr int m = decltype(m_)::value;
-                            f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                                for (int dx = 0; dx < 3; ++dx) {
-                                    const f32x4 xv = *(stream_lds_rd)(uintptr_t)(rowb[dy] + (unsigned)(16 * m + j + dx) * in_px + qoff);
-                                    d += dw[dy * 3 + dx] * xv;
-                                }
-                            if (!qv) d = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) {
-                                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[s][0], d[s], acc[m][0], 0, 0, 0);
-                                if (out_tiles > 1) acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[s][1], d[s], acc[m][1], 0, 0, 0);
-                            }
-                        });
-                    }
-                });
+                for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + c.in.off + (unsigned)((g + 2 * c.in.slots - 1 + dy) % c.in.slots) * in_row + (unsigned)(3 * j) * in_px;   // rows g-1, g, g+1
+                stream_dw_pw<CH, NT>(acc, lds0, rowb, in_px, c.in.quads, c.dww, c.wp, q, lane);
             }
 #pragma unroll
-            for (int m = 0; m < kStreamMT; ++m) {
-                const int cx = ri.sx + 16 * m + j;
-                const bool ok = !ri.zero && cx >= 0 && cx < a.W;
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const f32x4 bs = *reinterpret_cast<const f32x4*>(a.blob + c.ba + n * 16 + 4 * q);        // L1 hits: once per row
-                    const f32x4 al = *reinterpret_cast<const f32x4*>(a.blob + c.ba + 32 + n * 16 + 4 * q);
-                    const f32x4 r = stream_prelu(acc[m][n], bs, al);
-                    acc[m][n] = ok ? r : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                }
-            }
-            if (c.to_global && ri.store) {
+            for (int n = 0; n < NT; ++n) {
+                const f32x4 bs = stream_ld(lds0 + c.ba + (unsigned)(n * 4 + q) * 16u);
+                const f32x4 al = stream_ld(lds0 + c.ba + 128u + (unsigned)(n * 4 + q) * 16u);
 #pragma unroll
                 for (int m = 0; m < kStreamMT; ++m) {
-                    const int cx = ri.sx + 16 * m + j;
-                    if (cx >= ri.ux0 && cx < ri.ux1) {
-                        float* o = a.out + (((size_t)ri.img * a.H + ri.r) * a.W + cx) * a.out_stride;
-#pragma unroll
-                        for (int n = 0; n < 2; ++n)
-                            if (n * 4 + q < c.out.quads) *reinterpret_cast<f32x4*>(o + (n * 4 + q) * 4) = acc[m][n];
-                    }
+                    const int cx = ri.sx + 3 * j + m;
+                    const bool ok = !ri.zero && cx >= 0 && cx < a.W;
+                    const f32x4 r = stream_prelu(acc[m][n], bs, al);
+                    acc[m][n] = ok ? r : kStreamZero;
+                    if (c.to_global && ri.store && cx >= ri.ux0 && cx < ri.ux1 && n * 4 + q < c.out.quads)
+                        *reinterpret_cast<f32x4*>(a.out + (((size_t)ri.img * a.H + ri.r) * a.W + cx) * a.out_stride + (n * 4 + q) * 4) = acc[m][n];
                 }
             }
         }
@@ -238,17 +254,16 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
 #pragma unroll
             for (int m = 0; m < kStreamMT; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < NT; ++n)
                     if (n * 4 + q < c.out.quads)
-                        *(stream_lds_wr)(uintptr_t)(lds0 + c.out.off + ((slot * kStreamRowPx + 16 * m + j + 1) * c.out.units + n * 4 + q) * 16u) = acc[m][n];
+                        stream_st(lds0 + c.out.off + ((slot * kStreamRowPx + 3 * j + m + 1) * c.out.units + n * 4 + q) * 16u, acc[m][n]);
         }
         stream_barrier();
     }
 }
 
 // ---- A1 || B1: one (feature layer, row) contribution per step and wave --------------------------------------------
-__device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsigned lds0, int j0, int rows, int T, int lane) {
-    const int j = lane & 15, q = lane >> 4;
+__device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsigned lds0, int j0, int rows, int T, int) {
     const int L = a.L;
     f32x4 acc[2][kStreamMT][2];
 #pragma unroll
@@ -256,9 +271,14 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
 #pragma unroll
         for (int m = 0; m < kStreamMT; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) acc[p][m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int n = 0; n < 2; ++n) acc[p][m][n] = kStreamZero;
+    StreamCursor cur[2];       // the wave alternates between an even and an odd row; each advances by 2L rows at a time
 
     for (int t = 0; t < T; ++t) {
+        // (opaque per step: otherwise every lane-derived address of every branch is hoisted out of the loop and spilled)
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const int j = lane & 15, q = lane >> 4;
         // row g = t + 1 - 2l receives layer l's contribution at step t; (g >> 1) mod L == w picks this wave's l
         const int hl = (t + 1) >> 1;
         int l = ((hl - w) % L + L) % L;
@@ -266,50 +286,52 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
         const int g = t + 1 - 2 * l;
         const bool live = g >= 0 && g < rows;
         const bool last = l == L;
-        StreamRow ri{};
-        f32x4 b1v[kStreamMT];
         if (live) {
-            ri = stream_row(a, j0, g);
             const StreamNinSrc& s = a.nin[l - 1];
             auto body = [&](auto p_) DCSCN_INL {
                 constexpr int p = decltype(p_)::value;
+                const StreamRow ri = stream_row(a, j0, cur[p], g);
                 if (!ri.zero) {
-                    const unsigned rowb = lds0 + s.ring.off + (unsigned)(g % 3) * (unsigned)(kStreamRowPx * s.ring.units) * 16u;
+                    const unsigned rowb = lds0 + s.ring.off + ((unsigned)(g % 3) * kStreamRowPx + 3 * j + 1) * (unsigned)s.ring.units * 16u;
+#pragma unroll 1
                     for (int ch = 0; ch < s.chunks; ++ch) {
                         const int quad = ch * 4 + q;
                         const bool qv = quad < s.ring.quads;
                         const unsigned qoff = (unsigned)(qv ? quad : 0) * 16u;
-                        const f32x4 w0 = *(stream_lds_rd)(uintptr_t)(lds0 + s.w + (unsigned)((ch * 2 + 0) * 64 + lane) * 16u);
-                        const f32x4 w1 = *(stream_lds_rd)(uintptr_t)(lds0 + s.w + (unsigned)((ch * 2 + 1) * 64 + lane) * 16u);
-                        const int steps = ch == s.chunks - 1 ? s.last_steps : 4;
-                        static_for<0, kStreamMT>([&](auto m_) DCSCN_INL {
-                            constexpr int m = decltype(m_)::value;
-                            f32x4 xv = *(stream_lds_rd)(uintptr_t)(rowb + (unsigned)((16 * m + j + 1) * s.ring.units) * 16u + qoff);
-                            if (!qv) xv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        const f32x4 w0 = stream_ld(lds0 + s.w + (unsigned)((ch * 2 + 0) * 64 + lane) * 16u);
+                        const f32x4 w1 = stream_ld(lds0 + s.w + (unsigned)((ch * 2 + 1) * 64 + lane) * 16u);
+                        f32x4 xv[kStreamMT];
 #pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (k < steps) {
-                                    acc[p][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[k], xv[k], acc[p][m][0], 0, 0, 0);
-                                    acc[p][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[k], xv[k], acc[p][m][1], 0, 0, 0);
-                                }
-                        });
+                        for (int m = 0; m < kStreamMT; ++m) {
+                            xv[m] = stream_ld(rowb + (unsigned)(m * s.ring.units) * 16u + qoff);
+                            if (!qv) xv[m] = kStreamZero;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int m = 0; m < kStreamMT; ++m) {
+                                acc[p][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[k], xv[m][k], acc[p][m][0], 0, 0, 0);
+                                acc[p][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[k], xv[m][k], acc[p][m][1], 0, 0, 0);
+                            }
                     }
                 }
                 if (last) {
-                    // bias, PReLU; A1 -> Concat2 (global) now, the B1 quads (tile 0, nb <= 16) wait for the write phase
+                    // bias, PReLU; A1 -> Concat2 (global), the B1 quads (tile 0, nb <= 16) -> the B1 ring, which has a FOURTH slot so
+                    // that the row can be written while B2 reads the three before it (no registers held across the barrier)
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
-                        const f32x4 bs = *reinterpret_cast<const f32x4*>(a.blob + a.nin_ba + n * 16 + 4 * q);
-                        const f32x4 al = *reinterpret_cast<const f32x4*>(a.blob + a.nin_ba + 32 + n * 16 + 4 * q);
+                        const f32x4 bs = stream_ld(lds0 + a.nin_ba + (unsigned)(n * 4 + q) * 16u);
+                        const f32x4 al = stream_ld(lds0 + a.nin_ba + 128u + (unsigned)(n * 4 + q) * 16u);
                         const int quad = n * 4 + q;
 #pragma unroll
                         for (int m = 0; m < kStreamMT; ++m) {
-                            const int cx = ri.sx + 16 * m + j;
+                            const int cx = ri.sx + 3 * j + m;
                             const bool ok = !ri.zero && cx >= 0 && cx < a.W;
                             const f32x4 r = stream_prelu(acc[p][m][n], bs, al);
-                            const f32x4 v = ok ? r : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                            acc[p][m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                            if (n == 0) b1v[m] = v;
+                            const f32x4 v = ok ? r : kStreamZero;
+                            acc[p][m][n] = kStreamZero;
+                            if (n == 0 && q < a.nb_quads)
+                                stream_st(lds0 + a.b1.off + (((unsigned)(g & 3) * kStreamRowPx + 3 * j + m + 1) * a.b1.units + q) * 16u, v);
                             if (ri.store && cx >= ri.ux0 && cx < ri.ux1 && quad >= a.nb_quads && quad * 4 < a.out_stride)
                                 *reinterpret_cast<f32x4*>(a.out + (((size_t)ri.img * a.H + ri.r) * a.W + cx) * a.out_stride + quad * 4) = v;
                         }
@@ -320,13 +342,6 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
             else body(std::integral_constant<int, 0>{});
         }
         stream_barrier();
-        if (live && last) {
-            const unsigned slot = (unsigned)(g % 3);
-#pragma unroll
-            for (int m = 0; m < kStreamMT; ++m)
-                if (q < a.nb_quads)       // B1 lives in tile 0 (nb <= 16)
-                    *(stream_lds_wr)(uintptr_t)(lds0 + a.b1.off + ((slot * kStreamRowPx + 16 * m + j + 1) * a.b1.units + q) * 16u) = b1v[m];
-        }
         stream_barrier();
     }
 }
@@ -338,8 +353,7 @@ __global__ __launch_bounds__(1024) void feat_stream(const StreamArgs a) {
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
     {
         f32x4* s4 = reinterpret_cast<f32x4*>(smem);
-        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = tid; i < a.ring_bytes / 16; i += blockDim.x) s4[i] = z;
+        for (int i = tid; i < a.ring_bytes / 16; i += blockDim.x) s4[i] = kStreamZero;
         const f32x4* src = reinterpret_cast<const f32x4*>(a.blob + a.ldsw_src);
         for (int i = tid; i < a.ldsw_bytes / 16; i += blockDim.x) s4[a.ring_bytes / 16 + i] = src[i];
         __syncthreads();
@@ -349,8 +363,14 @@ __global__ __launch_bounds__(1024) void feat_stream(const StreamArgs a) {
     const int rows = (j1 - j0) * (a.rows_c + 1);
     const int T = rows + a.total_lag;
     if (wave == 0) stream_first_role(a, lds0, j0, rows, T, lane);
-    else if (wave <= a.n_conv) stream_conv_role(a, a.conv[wave - 1], lds0, j0, rows, T, lane);
-    else stream_nin_role(a, wave - 1 - a.n_conv, lds0, j0, rows, T, lane);
+    else if (wave <= a.n_conv) {
+        const StreamConv& c = a.conv[wave - 1];
+        const bool ch2 = c.in.quads > 4, nt2 = c.out.quads > 4;
+        if (ch2 && nt2) stream_conv_role<2, 2>(a, c, lds0, j0, rows, T, lane);
+        else if (ch2) stream_conv_role<2, 1>(a, c, lds0, j0, rows, T, lane);
+        else if (nt2) stream_conv_role<1, 2>(a, c, lds0, j0, rows, T, lane);
+        else stream_conv_role<1, 1>(a, c, lds0, j0, rows, T, lane);
+    } else stream_nin_role(a, wave - 1 - a.n_conv, lds0, j0, rows, T, lane);
 }
 
 }  // namespace dcscn

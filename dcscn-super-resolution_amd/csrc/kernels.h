@@ -102,16 +102,17 @@ constexpr int kStreamMaxL = 7;                 // feature layers (2L + 1 waves <
 constexpr int kStreamMT = kStreamPX / 16;
 
 struct StreamRing {
-    int32_t off;      // LDS byte offset of [3 slots][kStreamRowPx][units] float4
+    int32_t off;      // LDS byte offset of [slots][kStreamRowPx][units] float4
     int32_t units;    // 16-byte units per pixel (odd)
     int32_t quads;    // units that hold channels: pad4(C) / 4
+    int32_t slots;    // rows in the ring: 3 (written after the step's barrier) or 4 (written while its readers run)
 };
 struct StreamConv {   // separable 3x3 layer of the stream
     StreamRing in, out;
     int32_t lag;          // computes stream row t - lag at step t
     int32_t dww;          // LDS byte offset of the depthwise filter [9][in.quads] float4
-    int32_t wp;           // blob float offset of the pointwise filter [2 chunks][4 k-steps][2 tiles][64 lanes]
-    int32_t ba;           // blob float offset of bias[32], slope[32]
+    int32_t wp;           // LDS byte offset of the pointwise filter [chunk][tile][64 lanes] float4 (k-steps 0..3)
+    int32_t ba;           // LDS byte offset of bias[32], slope[32]
     int32_t to_global;    // 1: the layer stores to `out` channels [0, 4 * out.quads) instead of a ring (B2)
     int32_t pad_;
 };
@@ -137,7 +138,7 @@ struct StreamArgs {
     StreamConv conv[kStreamMaxL];          // CNN2 .. CNNL, B2
     StreamNinSrc nin[kStreamMaxL];
     StreamRing b1;
-    int32_t nin_ba;                        // blob offset of bias[32], slope[32] of [B1 | A1]
+    int32_t nin_ba;                        // LDS byte offset of bias[32], slope[32] of [B1 | A1]
     int32_t nb_quads;                      // channel quads of the B1 part
 };
 
