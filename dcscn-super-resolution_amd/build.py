@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_NAME = "libdcscn_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 SOURCES = ["api.hip", "kernels.hip", "resample.hip", "ensemble.hip", "color.hip", "conv_k1.hip", "conv_k3.hip", "conv_k5.hip", "conv_k7.hip", "conv_wino2.hip", "conv_nin.hip", "feat_stream.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "conv_igemm.hpp", "conv_wino2.hpp", "conv_nin.hpp", "conv_variants.hpp", "feat_stream.hpp")] + \
+HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "conv_igemm.hpp", "conv_wino2.hpp", "conv_nin.hpp", "conv_variants.hpp", "feat_stream.hpp", "tail_stream.hpp")] + \
           [os.path.join(INCLUDE, "dcscn.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

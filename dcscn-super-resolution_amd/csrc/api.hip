@@ -46,7 +46,7 @@ inline int pad4(int c) { return (c + 3) & ~3; }
 inline int pad16(int c) { return (c + 15) & ~15; }
 
 enum { EXT_X = -1, EXT_X2 = -2, EXT_Y = -3 };
-enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2, OP_COUT1 = 3, OP_STREAM = 4 };
+enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2, OP_COUT1 = 3, OP_STREAM = 4, OP_TAIL = 5 };
 
 struct TensorSpec {
     std::string name;
@@ -116,6 +116,7 @@ struct Op {
     // OP_STREAM (stream_features): the launches this op replaces, kept for their tensor indices, and the kernel plan
     std::vector<Op> fused;
     StreamArgs stream{};
+    TailArgs tail{};
     int halo = -1;                            // >= 0: receptive-field radius of the op in ITS pixels (else ks / 2)
 };
 
@@ -169,6 +170,7 @@ struct dcscn_ctx {
     bool has_last = false;
     bool profile = false;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
+    bool stream_tail = true;                 // the x4 tail of the same nets as one launch (fuse_tail_stream)
     bool stream_features = true;             // separable narrow nets: CNN1 .. B2 as one row-streamed launch (fuse_feat_stream)
     bool dense_features = true;              // per-layer feature buffers + multi-source NIN GEMM instead of one concat tensor (densify_features)
     int concat_buf = -1;                     // build_graph: the skip-concat buffer, its slices (offset, logical width)
@@ -720,9 +722,11 @@ int upload(dcscn_ctx* h, const void* host, size_t bytes, void** dev) {
 }
 
 int pack_feat_stream(dcscn_ctx* h, Op& op);
+int pack_tail_stream(dcscn_ctx* h, Op& op);
 
 int finalize_op(dcscn_ctx* h, Op& op) {
     if (op.kind == OP_STREAM) return pack_feat_stream(h, op);
+    if (op.kind == OP_TAIL) return pack_tail_stream(h, op);
     if (op.kind == OP_DW) {
         const TensorSpec& w = h->tensors[op.dw_w];          // [k, k, cin, 1] -> [taps][cin]
         int rc = upload(h, w.data.data(), w.data.size() * sizeof(float), (void**)&op.d_w);
@@ -1025,6 +1029,28 @@ inline float* buf_ptr(dcscn_ctx* h, int id) { return reinterpret_cast<float*>(st
 int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, const float* x2, float* y,
               hipStream_t stream) {
     const int Hr = H * op.res, Wr = W * op.res;
+    if (op.kind == OP_TAIL) {
+        TailArgs a = op.tail;
+        a.c2 = buf_ptr(h, op.in_buf);
+        a.c2_stride = h->bufs[op.in_buf].stride;
+        a.x2 = x2;
+        a.y = y;
+        a.blob = op.d_w;
+        a.N = nb; a.H = H; a.W = W;
+        a.halo = 2;
+        if (W <= kStreamPX) { a.n_strips = 1; a.useful_w = W; }
+        else { a.useful_w = kStreamPX - 2 * a.halo; a.n_strips = (W + a.useful_w - 1) / a.useful_w; }
+        const int64_t cols = (int64_t)nb * a.n_strips;
+        const int want = (int)std::max<int64_t>(1, (512 + cols - 1) / cols);
+        a.useful_h = std::max(32, (H + want - 1) / want);
+        a.n_blocks = (H + a.useful_h - 1) / a.useful_h;
+        a.rows_c = a.n_blocks == 1 ? H : a.useful_h + 2 * a.halo;
+        a.n_jobs = (int)(cols * a.n_blocks);
+        a.jobs_per_wg = (a.n_jobs + 255) / 256;
+        const int grid = (a.n_jobs + a.jobs_per_wg - 1) / a.jobs_per_wg;
+        HIP_TRY(h, tail_launch(a, grid, stream));
+        return DCSCN_OK;
+    }
     if (op.kind == OP_STREAM) {
         StreamArgs a = op.stream;
         a.x = x;
@@ -1552,6 +1578,124 @@ void fuse_feat_stream(dcscn_ctx* h) {
     h->concat_buf = -1;                                    // nothing left for densify_features
 }
 
+// The x4 tail of the same nets: Up-PS, Up-PS2 (each separable 3x3 + depth_to_space(2)) and the separable 1 -> 1 R-CNN1 with
+// the residual add become ONE launch (tail_stream.hpp); the C-channel tensor at 2x resolution stays in LDS.
+void fuse_tail_stream(dcscn_ctx* h) {
+    const dcscn_config& c = h->cfg;
+    if (!h->stream_tail || !c.depthwise_separable || c.cnn_size != 3 || c.scale != 4 || !c.pixel_shuffler || h->ops.size() < 3) return;
+    const size_t n = h->ops.size();
+    const Op& u1 = h->ops[n - 3];
+    const Op& u2 = h->ops[n - 2];
+    const Op& rc = h->ops[n - 1];
+    auto is_up = [](const Op& o) { return o.kind == OP_CONV && o.dwk == 3 && o.ks == 1 && o.segs.size() == 1 && o.act == ACT_NONE && o.ps == 2 && o.tconv_s == 0 && o.fold_s == 0; };
+    if (!is_up(u1) || !is_up(u2) || u1.res != 1 || u2.res != 2) return;
+    if (u1.cin <= 16 || u1.cin > 32 || u1.cin % 4 != 0 || u1.ps_c <= 16 || u1.ps_c > 32 || u1.ps_c % 4 != 0) return;
+    if (u2.cin != u1.ps_c || u2.ps_c != 1 || u2.in_buf != u1.out_buf[0]) return;
+    for (int i = 0; i < u1.cin; ++i)
+        if (u1.chan_map[i] != i) return;
+    if (u1.in_off != 0) return;
+    if (rc.kind != OP_COUT1 || rc.dw_w < 0 || rc.ks != 3 || !rc.residual || rc.in_buf != u2.out_buf[0] || rc.res != 4) return;
+
+    Op f;
+    f.kind = OP_TAIL;
+    f.name = u1.name.substr(0, u1.name.find('/')) + ".." + rc.name + " (streamed)";
+    f.ks = 3;
+    f.cin = u1.cin;
+    f.cout = 1;
+    f.res = 1;
+    f.in_buf = u1.in_buf;
+    f.cin_phys = u1.cin_phys;
+    f.residual = true;
+    f.halo = 2;
+    f.macs = u1.macs + u2.macs + rc.macs;
+    f.bytes = 4 * (int64_t)u1.cin_phys + 4 * 16 * 2;
+    f.fused = {u1, u2, rc};
+    const int dead[2] = {u1.out_buf[0], u2.out_buf[0]};
+    h->ops.erase(h->ops.end() - 3, h->ops.end());
+    h->ops.push_back(f);
+    for (int d : dead)
+        if (d >= 0) h->bufs[d].stride = 0;
+}
+
+int pack_tail_stream(dcscn_ctx* h, Op& op) {
+    const Op& u1 = op.fused[0];
+    const Op& u2 = op.fused[1];
+    const Op& rc = op.fused[2];
+    const int cin = u1.cin, C = u1.ps_c;
+    TailArgs& a = op.tail;
+    a = TailArgs{};
+    auto tens = [&](int id) -> const std::vector<float>& { return h->tensors[id].data; };
+    int lds = 0;
+    a.in.quads = cin / 4; a.in.units = a.in.quads | 1; a.in.slots = 3; a.in.off = lds;
+    lds += 3 * kStreamRowPx * a.in.units * 16;
+    a.u.quads = C / 4; a.u.units = a.u.quads | 1; a.u.slots = 6; a.u.off = lds;
+    lds += 6 * (2 * kStreamPX + 2) * a.u.units * 16;
+    a.v_off = lds;
+    lds += 12 * (4 * kStreamPX + 4) * 4;
+    a.ring_bytes = lds;
+    std::vector<float> blob;
+    auto region = [&](size_t floats) { const size_t base = blob.size(); blob.resize(base + floats, 0.0f); lds += (int)floats * 4; return base; };
+    // Up-PS
+    a.a_dww = lds;
+    {
+        const size_t base = region((size_t)9 * a.in.quads * 4);
+        const std::vector<float>& dw = tens(u1.dw_w);                 // [3, 3, cin, 1]
+        for (int k = 0; k < 9; ++k)
+            for (int ci = 0; ci < cin; ++ci) blob[base + (size_t)k * a.in.quads * 4 + ci] = dw[(size_t)k * cin + ci];
+    }
+    a.a_wp = lds;
+    {
+        const size_t base = region((size_t)4 * 2 * 2 * 64 * 4);
+        const ColSeg& sg = u1.segs[0];
+        const std::vector<float>& pw = tens(sg.w);                    // [1, 1, cin, 4C]: column phase * C + c
+        for (int ph = 0; ph < 4; ++ph)
+            for (int ch = 0; ch < 2; ++ch)
+                for (int n = 0; n < 2; ++n)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int st = 0; st < 4; ++st) {
+                            const int ci = 16 * ch + 4 * (lane >> 4) + st, cc = 16 * n + (lane & 15);
+                            if (ci < cin && cc < C) blob[base + ((((size_t)ph * 2 + ch) * 2 + n) * 64 + lane) * 4 + st] = pw[(size_t)ci * 4 * C + ph * C + cc];
+                        }
+    }
+    a.a_bias = lds;
+    {
+        const size_t base = region(4 * 32);
+        const ColSeg& sg = u1.segs[0];
+        for (int ph = 0; ph < 4; ++ph)
+            for (int cc = 0; cc < C; ++cc) blob[base + ph * 32 + cc] = sg.b >= 0 ? tens(sg.b)[ph * C + cc] : 0.0f;
+    }
+    // Up-PS2
+    a.b_dww = lds;
+    {
+        const size_t base = region((size_t)9 * a.u.quads * 4);
+        const std::vector<float>& dw = tens(u2.dw_w);                 // [3, 3, C, 1]
+        for (int k = 0; k < 9; ++k)
+            for (int ci = 0; ci < C; ++ci) blob[base + (size_t)k * a.u.quads * 4 + ci] = dw[(size_t)k * C + ci];
+    }
+    a.b_wp = lds;
+    {
+        const size_t base = region((size_t)2 * 64 * 4);
+        const std::vector<float>& pw = tens(u2.segs[0].w);            // [1, 1, C, 4]
+        for (int ch = 0; ch < 2; ++ch)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int st = 0; st < 4; ++st) {
+                    const int ci = 16 * ch + 4 * (lane >> 4) + st, co = lane & 15;
+                    if (ci < C && co < 4) blob[base + ((size_t)ch * 64 + lane) * 4 + st] = pw[(size_t)ci * 4 + co];
+                }
+    }
+    a.b_bias = lds;
+    {
+        const size_t base = region(4);
+        const ColSeg& sg = u2.segs[0];
+        for (int co = 0; co < 4; ++co) blob[base + co] = sg.b >= 0 ? tens(sg.b)[co] : 0.0f;
+    }
+    a.ldsw_bytes = lds - a.ring_bytes;
+    if (lds > 160 * 1024) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: tail_stream needs %d bytes of LDS", lds);
+    for (int k = 0; k < 9; ++k) a.c_w[k] = tens(rc.dw_w)[k];         // [3, 3, 1, 1]
+    a.c_scale = tens(rc.segs[0].w)[0];                               // [1, 1, 1, 1]
+    return upload(h, blob.data(), blob.size() * sizeof(float), (void**)&op.d_w);
+}
+
 int pack_feat_stream(dcscn_ctx* h, Op& op) {
     const dcscn_config& c = h->cfg;
     const int L = c.layers, nb = c.nin_filters2, na = c.nin_filters;
@@ -1742,6 +1886,7 @@ int dcscn_finalize(dcscn_handle h) {
         if (!t.set) return fail(h, DCSCN_ERR_MISSING_TENSOR, "variable '%s' was never set", t.name.c_str());
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->fold_tail) fold_linear_tail(h);      // silently keeps the layer-by-layer graph where it does not apply
+    fuse_tail_stream(h);
     fuse_feat_stream(h);
     densify_features(h);
     for (Op& op : h->ops) {
@@ -1775,7 +1920,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     const Op& op = h->ops[index];
     memset(out, 0, sizeof *out);
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
-    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : "depthwise");
+    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
     out->out_channels = op.cout;
@@ -1823,6 +1968,11 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "fold_linear_tail")) {
         if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the fold_linear_tail option must be set before dcscn_finalize");
         h->fold_tail = value != 0;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "stream_tail")) {
+        if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the stream_tail option must be set before dcscn_finalize");
+        h->stream_tail = value != 0;
         return DCSCN_OK;
     }
     if (!strcmp(key, "stream_features")) {

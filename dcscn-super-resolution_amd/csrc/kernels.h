@@ -142,6 +142,27 @@ struct StreamArgs {
     int32_t nb_quads;                      // channel quads of the B1 part
 };
 
+
+// ---- row-streamed x4 upsampler + reconstruction of the separable narrow nets (tail_stream.hpp) ----
+struct TailArgs {
+    const float* c2;      // Concat2 [N, H, W, c2_stride]
+    const float* x2;      // bicubic image [N, 4H, 4W]
+    float* y;             // [N, 4H, 4W]
+    const float* blob;    // LDS image of the filters (api.hip: pack_tail_stream)
+    int32_t c2_stride;
+    int32_t N, H, W;
+    int32_t n_strips, useful_w, halo;
+    int32_t n_blocks, useful_h, rows_c;
+    int32_t n_jobs, jobs_per_wg;
+    StreamRing in, u;     // IN: 3 rows x 50 pixels of Concat2; U: 6 rows x 98 pixels of the first depth_to_space output
+    int32_t v_off;        // V: 12 rows x 196 floats, the second depth_to_space output (1 channel)
+    int32_t ring_bytes, ldsw_bytes;
+    int32_t a_dww, a_wp, a_bias;    // Up-PS: depthwise [9][in.quads] float4, pointwise [4 phases][2][2][64] float4, bias [4 phases][8] float4
+    int32_t b_dww, b_wp, b_bias;    // Up-PS2: depthwise [9][u.quads] float4, pointwise [2][1][64] float4, bias float4
+    float c_w[9];         // R-CNN1 depthwise filter
+    float c_scale;        // R-CNN1 pointwise scalar
+};
+hipError_t tail_launch(const TailArgs& a, int grid, hipStream_t stream);
 void stream_init_kernels();
 hipError_t stream_launch(const StreamArgs& a, int grid, hipStream_t stream);
 

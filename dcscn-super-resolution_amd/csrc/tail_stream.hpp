@@ -1,0 +1,245 @@
+// Row-streamed x4 upsampler + reconstruction of the separable narrow nets: Up-PS (separable 3x3, C -> 4C) + depth_to_space(2),
+// Up-PS2 (separable 3x3, C -> 4) + depth_to_space(2), R-CNN1 (separable 3x3, 1 -> 1) + the bicubic residual
+// (DCSCN.py:293-325 with tf_graph.py:155-177, 239-249) in ONE launch.  Layer by layer the C-channel tensor at twice the
+// resolution (512 B per LR pixel) is written and read back through HBM -- two thirds of the tail's time; here it lives in
+// a six-row LDS ring.
+//
+// Same machinery as feat_stream.hpp (48-column strips, one LR row per step, compute phase / barrier / write phase /
+// barrier, jobs streamed back to back behind one zero row), with these roles:
+//
+//   wave 0        loads Concat2 row t+1 into registers while row t waits for its write phase -> IN ring (3 rows)
+//   waves 1..4    Up-PS, one sub-pixel phase (dy, dx) each: depthwise from IN, pointwise C -> C of that phase (MFMA), bias
+//                 -> row 2g+dy, pixels 2x+dx of the U ring (6 rows of 96 pixels x C channels)
+//   waves 5..8    Up-PS2 for one of the two new U rows x one 48-pixel half: depthwise from U, pointwise C -> 4 (MFMA, one
+//                 tile of which 4 columns are real), bias -> depth_to_space -> 2 rows x 96 pixels of the V ring (1 channel,
+//                 12 rows of 192 pixels)
+//   waves 9..10   R-CNN1 on two of the four new HR rows each: 3x3 on V, the pointwise scalar, + x2 -> y (global)
+//
+// Lags: Up-PS runs 2 LR rows behind the loader, Up-PS2 2 behind Up-PS, R-CNN1 2 behind Up-PS2.
+#pragma once
+#include "feat_stream.hpp"
+
+namespace dcscn {
+
+constexpr int kTailURowPx = 2 * kStreamPX + 2;      // U ring row: pixels -1 .. 96
+constexpr int kTailUSlots = 6;
+constexpr int kTailVRow = 4 * kStreamPX + 4;        // V ring row in floats: 2 zero floats, 192 pixels, 2 zero floats
+constexpr int kTailVSlots = 12;
+
+__device__ __forceinline__ StreamArgs tail_geometry(const TailArgs& a) {
+    // stream_row only looks at the job geometry
+    StreamArgs g{};
+    g.H = a.H; g.W = a.W;
+    g.n_strips = a.n_strips; g.useful_w = a.useful_w; g.halo = a.halo;
+    g.n_blocks = a.n_blocks; g.useful_h = a.useful_h; g.rows_c = a.rows_c;
+    return g;
+}
+
+// ---- loader: Concat2 rows -> IN ring -------------------------------------------------------------------------------
+__device__ __forceinline__ void tail_load_role(const TailArgs& a, const StreamArgs& geo, unsigned lds0, int j0, int rows, int T, int lane) {
+    constexpr int ITEMS = (kStreamPX * 8 + 63) / 64;      // float4 items per lane (up to 8 quads per pixel)
+    const int n_items = kStreamPX * a.in.quads;
+    StreamCursor cur;
+    f32x4 now[ITEMS], nxt[ITEMS];
+    auto load_row = [&](int gs, f32x4 (&dst)[ITEMS]) DCSCN_INL {
+        const bool in = gs >= 0 && gs < rows;
+        const StreamRow ri = stream_row(geo, j0, cur, in ? gs : 0);
+        const bool live = in && !ri.zero;
+        const float* row = a.c2 + ((size_t)ri.img * a.H + (live ? ri.r : 0)) * a.W * a.c2_stride;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int it = lane + 64 * i;
+            const int px = it / a.in.quads, quad = it - px * a.in.quads;
+            const int cx = ri.sx + px;
+            dst[i] = live && it < n_items && cx >= 0 && cx < a.W ? *reinterpret_cast<const f32x4*>(row + (size_t)cx * a.c2_stride + 4 * quad) : kStreamZero;
+        }
+    };
+    load_row(0, now);
+    for (int t = 0; t < T; ++t) {
+        load_row(t + 1, nxt);
+        stream_barrier();
+        if (t < rows) {
+            const unsigned slot = (unsigned)(t % 3);
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int it = lane + 64 * i;
+                const int px = it / a.in.quads, quad = it - px * a.in.quads;
+                if (it < n_items) stream_st(lds0 + a.in.off + ((slot * kStreamRowPx + px + 1) * a.in.units + quad) * 16u, now[i]);
+            }
+        }
+        stream_barrier();
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) now[i] = nxt[i];
+    }
+}
+
+// ---- Up-PS, one sub-pixel phase ------------------------------------------------------------------------------------
+__device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArgs& geo, int phase, unsigned lds0, int j0, int rows, int T, int lane) {
+    const int j = lane & 15, q = lane >> 4;
+    const int dy_o = phase >> 1, dx_o = phase & 1;
+    const unsigned in_px = (unsigned)a.in.units * 16u, in_row = (unsigned)kStreamRowPx * in_px;
+    const unsigned u_px = (unsigned)a.u.units * 16u, u_row = (unsigned)kTailURowPx * u_px;
+    StreamCursor cur;
+    for (int t = 0; t < T; ++t) {
+        const int g = t - 2;
+        const bool live = g >= 0 && g < rows;
+        f32x4 acc[kStreamMT][2];
+#pragma unroll
+        for (int m = 0; m < kStreamMT; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = kStreamZero;
+        if (live) {
+            const StreamRow ri = stream_row(geo, j0, cur, g);
+            if (!ri.zero) {
+                unsigned rowb[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + a.in.off + (unsigned)((g + 2 + dy) % 3) * in_row + (unsigned)(3 * j) * in_px;
+                stream_dw_pw<2, 2>(acc, lds0, rowb, in_px, a.in.quads, a.a_dww, a.a_wp + phase * (2 * 2 * 64 * 16), q, lane);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const f32x4 bs = stream_ld(lds0 + a.a_bias + (unsigned)(phase * 8 + n * 4 + q) * 16u);
+#pragma unroll
+                for (int m = 0; m < kStreamMT; ++m) {
+                    const int cx = ri.sx + 3 * j + m;
+                    const bool ok = !ri.zero && cx >= 0 && cx < a.W;
+                    acc[m][n] = ok ? acc[m][n] + bs : kStreamZero;
+                }
+            }
+        }
+        stream_barrier();
+        if (live) {
+            const unsigned slot = (unsigned)((2 * g + dy_o) % kTailUSlots);
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    if (n * 4 + q < a.u.quads)
+                        stream_st(lds0 + a.u.off + slot * u_row + (unsigned)(2 * (3 * j + m) + dx_o + 1) * u_px + (unsigned)(n * 4 + q) * 16u, acc[m][n]);
+        }
+        stream_barrier();
+    }
+}
+
+// ---- Up-PS2 on U row 2g + r2, pixels 48 * half .. + 47 ------------------------------------------------------------------
+__device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArgs& geo, int r2, int half, unsigned lds0, int j0, int rows, int T, int lane) {
+    const int j = lane & 15, q = lane >> 4;
+    const unsigned u_px = (unsigned)a.u.units * 16u, u_row = (unsigned)kTailURowPx * u_px;
+    StreamCursor cur;
+    for (int t = 0; t < T; ++t) {
+        const int g = t - 4;
+        const bool live = g >= 0 && g < rows;
+        f32x4 acc[kStreamMT][1];
+#pragma unroll
+        for (int m = 0; m < kStreamMT; ++m) acc[m][0] = kStreamZero;
+        if (live) {
+            const StreamRow ri = stream_row(geo, j0, cur, g);
+            if (!ri.zero) {
+                const int ur = 2 * g + r2;
+                unsigned rowb[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+                    rowb[dy] = lds0 + a.u.off + (unsigned)((ur - 1 + dy + kTailUSlots) % kTailUSlots) * u_row + (unsigned)(kStreamPX * half + 3 * j) * u_px;
+                stream_dw_pw<2, 1>(acc, lds0, rowb, u_px, a.u.quads, a.b_dww, a.b_wp, q, lane);
+            }
+            const f32x4 bs = stream_ld(lds0 + a.b_bias);
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m) {
+                const int cx2 = 2 * ri.sx + kStreamPX * half + 3 * j + m;
+                const bool ok = !ri.zero && cx2 >= 0 && cx2 < 2 * a.W;
+                acc[m][0] = ok ? acc[m][0] + bs : kStreamZero;
+            }
+        }
+        stream_barrier();
+        if (live && q == 0) {
+            // depth_to_space(2) of the 4 channels: (v.x v.y / v.z v.w) -> HR rows 4g + 2 r2 + {0, 1}, pixels 2 px2 + {0, 1}
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef __attribute__((address_space(3))) f32x2* lds_f2;
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m) {
+                const int px4 = 2 * (kStreamPX * half + 3 * j + m);
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const unsigned slot = (unsigned)((4 * g + 2 * r2 + dy) % kTailVSlots);
+                    const f32x2 v = dy == 0 ? f32x2{acc[m][0].x, acc[m][0].y} : f32x2{acc[m][0].z, acc[m][0].w};
+                    *(lds_f2)(uintptr_t)(lds0 + a.v_off + (slot * kTailVRow + px4 + 2) * 4u) = v;
+                }
+            }
+        }
+        stream_barrier();
+    }
+}
+
+// ---- R-CNN1 + residual on HR rows 4g + 2c + {0, 1} -----------------------------------------------------------------------
+__device__ __forceinline__ void tail_rec_role(const TailArgs& a, const StreamArgs& geo, int c, unsigned lds0, int j0, int rows, int T, int lane) {
+    typedef const __attribute__((address_space(3))) float* lds_f1;
+    StreamCursor cur;
+    const int W4 = 4 * a.W;
+    for (int t = 0; t < T; ++t) {
+        const int g = t - 6;
+        const bool live = g >= 0 && g < rows;
+        if (live) {
+            const StreamRow ri = stream_row(geo, j0, cur, g);
+            if (ri.store) {
+                const int vr0 = 4 * g + 2 * c;                  // first output row in V-row numbering
+                const int cx0 = 4 * ri.sx + 3 * lane;           // first of the lane's three HR columns
+                float res[2][3];
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int cx = cx0 + k;
+                        const bool ok = cx >= 4 * ri.ux0 && cx < 4 * ri.ux1;
+                        res[e][k] = ok ? a.x2[((size_t)ri.img * 4 * a.H + 4 * ri.r + 2 * c + e) * W4 + cx] : 0.0f;
+                    }
+                float v[4][5];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const unsigned slot = (unsigned)((vr0 - 1 + rr + kTailVSlots) % kTailVSlots);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) v[rr][k] = *(lds_f1)(uintptr_t)(lds0 + a.v_off + (slot * kTailVRow + 3 * lane + k + 1) * 4u);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float s = 0.0f;
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx) s = fmaf(a.c_w[dy * 3 + dx], v[e + dy][k + dx], s);
+                        const int cx = cx0 + k;
+                        if (cx >= 4 * ri.ux0 && cx < 4 * ri.ux1)
+                            a.y[((size_t)ri.img * 4 * a.H + 4 * ri.r + 2 * c + e) * W4 + cx] = s * a.c_scale + res[e][k];
+                    }
+            }
+        }
+        stream_barrier();
+        stream_barrier();
+    }
+}
+
+__global__ __launch_bounds__(704) void tail_stream(const TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    {
+        f32x4* s4 = reinterpret_cast<f32x4*>(smem);
+        for (int i = tid; i < a.ring_bytes / 16; i += blockDim.x) s4[i] = kStreamZero;
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.blob);
+        for (int i = tid; i < a.ldsw_bytes / 16; i += blockDim.x) s4[a.ring_bytes / 16 + i] = src[i];
+        __syncthreads();
+    }
+    const StreamArgs geo = tail_geometry(a);
+    const int j0 = blockIdx.x * a.jobs_per_wg;
+    const int j1 = min(a.n_jobs, j0 + a.jobs_per_wg);
+    const int rows = (j1 - j0) * (a.rows_c + 1);
+    const int T = rows + 6;
+    if (wave == 0) tail_load_role(a, geo, lds0, j0, rows, T, lane);
+    else if (wave <= 4) tail_up1_role(a, geo, wave - 1, lds0, j0, rows, T, lane);
+    else if (wave <= 8) tail_up2_role(a, geo, (wave - 5) >> 1, (wave - 5) & 1, lds0, j0, rows, T, lane);
+    else tail_rec_role(a, geo, wave - 9, lds0, j0, rows, T, lane);
+}
+
+}  // namespace dcscn

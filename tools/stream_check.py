@@ -26,6 +26,7 @@ engs = {}
 for mode in (1, 0):
     e = engine.Engine(cfg, device=0)
     e.set_option("stream_features", mode)
+    e.set_option("stream_tail", mode)
     e.load_weights(weights)
     engs[mode] = e
 print("ops streamed:", [o["kernel"] for o in engs[1].ops()])
