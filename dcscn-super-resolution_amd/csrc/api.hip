@@ -1512,6 +1512,22 @@ int dcscn_set_tensor(dcscn_handle h, const char* name, const float* data, const 
 
 namespace {
 // ---- row-streamed feature extractor (feat_stream.hpp) ---------------------------------------------------
+// Channel that lane group q (= lane >> 4) feeds into k-step s of 16-channel chunk ch, for an input ring of `quads` channel
+// quads (feat_stream.hpp: StreamChunk); -1 = none (the filter row stays zero).
+int stream_chunk_channel(int quads, int ch, int q, int s) {
+    const int chunks = (quads + 3) / 4;
+    const int ql = ch == chunks - 1 ? quads - 4 * (chunks - 1) : 4;
+    if (ql >= 3) return q < ql ? 16 * ch + 4 * q + s : -1;
+    if (ql == 2) return s < 2 ? 16 * ch + 4 * (q & 1) + 2 * (q >> 1) + s : -1;
+    return s == 0 ? 16 * ch + q : -1;
+}
+// the (input quads, output tiles) pairs stream_conv_role is instantiated for (feat_stream.hpp: feat_stream)
+bool stream_conv_supported(int in_quads, int out_tiles) {
+    if (in_quads <= 5) return out_tiles == 1;
+    if (in_quads <= 7) return out_tiles == 2;
+    return true;
+}
+
 // The separable narrow nets (depthwise_separable, <= 7 feature layers of <= 32 filters, NIN of <= 32 channels): the
 // launches CNN1/depthwise, CNN1 .. CNNL, B1+A1, B2 become ONE launch that keeps every intermediate tensor in LDS.
 void fuse_feat_stream(dcscn_ctx* h) {
@@ -1535,6 +1551,10 @@ void fuse_feat_stream(dcscn_ctx* h) {
     if (nin.kind != OP_CONV || nin.ks != 1 || nin.dwk != 0 || nin.segs.size() != 2 || nin.act != ACT_ALPHA || !is_ds3(b2)) return;
     if (b2.out_buf[0] != nin.out_buf[1] || b2.out_off[0] != 0 || nin.out_off[1] != pad4(c.nin_filters2)) return;
 
+    for (int i = 0; i < L; ++i) {
+        const int cin = i == L - 1 ? c.nin_filters2 : h->sched[i], cout = i == L - 1 ? c.nin_filters2 : h->sched[i + 1];
+        if (!stream_conv_supported(pad4(cin) / 4, (cout + 15) / 16)) return;
+    }
     // LDS budget: rings + the filters that are indexed by a run-time layer (A1 || B1 slices, depthwise)
     auto units = [](int ch) { const int q = pad4(ch) / 4; return q | 1; };
     size_t lds = 0;
@@ -1653,8 +1673,8 @@ int pack_tail_stream(dcscn_ctx* h, Op& op) {
                 for (int n = 0; n < 2; ++n)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int st = 0; st < 4; ++st) {
-                            const int ci = 16 * ch + 4 * (lane >> 4) + st, cc = 16 * n + (lane & 15);
-                            if (ci < cin && cc < C) blob[base + ((((size_t)ph * 2 + ch) * 2 + n) * 64 + lane) * 4 + st] = pw[(size_t)ci * 4 * C + ph * C + cc];
+                            const int ci = stream_chunk_channel(cin / 4, ch, lane >> 4, st), cc = 16 * n + (lane & 15);
+                            if (ci >= 0 && ci < cin && cc < C) blob[base + ((((size_t)ph * 2 + ch) * 2 + n) * 64 + lane) * 4 + st] = pw[(size_t)ci * 4 * C + ph * C + cc];
                         }
     }
     a.a_bias = lds;
@@ -1679,8 +1699,8 @@ int pack_tail_stream(dcscn_ctx* h, Op& op) {
         for (int ch = 0; ch < 2; ++ch)
             for (int lane = 0; lane < 64; ++lane)
                 for (int st = 0; st < 4; ++st) {
-                    const int ci = 16 * ch + 4 * (lane >> 4) + st, co = lane & 15;
-                    if (ci < C && co < 4) blob[base + ((size_t)ch * 64 + lane) * 4 + st] = pw[(size_t)ci * 4 + co];
+                    const int ci = stream_chunk_channel(C / 4, ch, lane >> 4, st), co = lane & 15;
+                    if (ci >= 0 && ci < C && co < 4) blob[base + ((size_t)ch * 64 + lane) * 4 + st] = pw[(size_t)ci * 4 + co];
                 }
     }
     a.b_bias = lds;
@@ -1733,8 +1753,7 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
         StreamNinSrc& s = a.nin[i];
         s.ring = fr[i];
         s.chunks = (C + 15) / 16;
-        const int rem = C - 16 * (s.chunks - 1);
-        s.last_steps = rem >= 4 ? 4 : rem;
+        s.last_ql = s.ring.quads - 4 * (s.chunks - 1);
         s.w = lds;
         const size_t base = blob.size();
         blob.resize(base + (size_t)s.chunks * 2 * 64 * 4, 0.0f);
@@ -1742,8 +1761,8 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
             for (int n = 0; n < 2; ++n)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int k = 0; k < 4; ++k) {
-                        const int ci = 16 * ch + 4 * (lane >> 4) + k, v = 16 * n + (lane & 15);
-                        if (ci >= C) continue;
+                        const int ci = stream_chunk_channel(s.ring.quads, ch, lane >> 4, k), v = 16 * n + (lane & 15);
+                        if (ci < 0 || ci >= C) continue;
                         const ColSeg* sg = nullptr;
                         int co = 0;
                         if (v < pad4(nb)) { if (v < nb) { sg = &sb; co = v; } }
@@ -1798,8 +1817,8 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
             for (int n = 0; n < tiles; ++n)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int st = 0; st < 4; ++st) {
-                        const int ci = 16 * ch + 4 * (lane >> 4) + st, co = 16 * n + (lane & 15);
-                        if (ci < cin && co < cout) blob[base + ((size_t)(ch * tiles + n) * 64 + lane) * 4 + st] = pw[(size_t)ci * cout + co];
+                        const int ci = stream_chunk_channel(pad4(cin) / 4, ch, lane >> 4, st), co = 16 * n + (lane & 15);
+                        if (ci >= 0 && ci < cin && co < cout) blob[base + ((size_t)(ch * tiles + n) * 64 + lane) * 4 + st] = pw[(size_t)ci * cout + co];
                     }
         lds += chunks * tiles * 64 * 16;
         cv.ba = lds;

@@ -31,6 +31,10 @@
 #pragma once
 #include "conv_igemm.hpp"
 
+#ifndef STREAM_ABL
+#define STREAM_ABL 0      // tools/stream_abl.sh: timing-only builds with one cost removed (results wrong by design)
+#endif
+
 namespace dcscn {
 
 typedef const __attribute__((address_space(3))) f32x4* stream_lds_rd;
@@ -120,7 +124,7 @@ __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned 
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int cx = ri.sx + 3 * j + k - 1;
-            dst[k] = live && cx >= 0 && cx < a.W ? row[cx] : 0.0f;
+            dst[k] = live && cx >= 0 && cx < a.W && STREAM_ABL != 7 && STREAM_ABL != 8 ? row[cx] : 0.0f;
         }
     };
 #pragma unroll
@@ -167,55 +171,79 @@ __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned 
     }
 }
 
+// K-step bookkeeping of a 16-channel chunk that holds QL (1..4) valid channel quads.  A lane (q = lane >> 4) always
+// reads one float4 = one quad; with 4 or 3 valid quads lane q feeds element s of quad q into k-step s (4 k-steps, the
+// lanes of a missing quad multiply zero filter rows).  With 2 valid quads the lanes q = 2, 3 read quads 0, 1 again and
+// feed their elements 2, 3: all 8 channels in 2 k-steps.  With 1 valid quad every lane reads it and feeds element q:
+// 1 k-step.  The filter images are packed to match (api.hip: stream_chunk_channel).
+template <int QL> struct StreamChunk {
+    static constexpr int STEPS = QL >= 3 ? 4 : QL;
+    static __device__ __forceinline__ int quad(int q) { return QL >= 3 ? (q < QL ? q : QL - 1) : QL == 2 ? (q & 1) : 0; }
+    static __device__ __forceinline__ float pick(const f32x4& d, int s, int q) {
+        if (QL >= 3) return d[s];
+        if (QL == 2) return q >= 2 ? d[s + 2] : d[s];
+        return q == 0 ? d[0] : q == 1 ? d[1] : q == 2 ? d[2] : d[3];
+    }
+};
+
 // The depthwise 3x3 + pointwise core shared by every separable layer of the streamed kernels: rowb[dy] = LDS address of
 // (row dy, the lane's first window pixel, quad 0); the lane's three pixels are window positions 0..2, 1..3, 2..4.
-// acc[m][n] += sum over chunks / k-steps of pointwise[n] x depthwise(pixel m).
-template <int CH, int NT>
-__device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[kStreamMT][NT], unsigned lds0, const unsigned (&rowb)[3], unsigned in_px,
-                                             int in_quads, int dww, int wpo, int q, int lane) {
+// acc[m][n] += sum over chunks / k-steps of pointwise[n] x depthwise(pixel m).  QUADS = channel quads of the input ring
+// (compile time: every LDS offset below is an immediate).
+template <int QUADS, int NT>
+__device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[kStreamMT][NT], unsigned lds0, const unsigned (&rowb)[3], int dww, int wpo, int q, int lane) {
+    constexpr int CH = (QUADS + 3) / 4;
+    constexpr unsigned PX = (unsigned)(QUADS | 1) * 16u;
     static_for<0, CH>([&](auto ch_) DCSCN_INL {
         constexpr int ch = decltype(ch_)::value;
-        const int quad = ch * 4 + q;
-        const bool qv = quad < in_quads;
-        const unsigned qoff = (unsigned)(qv ? quad : 0) * 16u;
+        constexpr int QL = ch == CH - 1 ? QUADS - 4 * (CH - 1) : 4;
+        using K = StreamChunk<QL>;
+        const unsigned qoff = (unsigned)(ch * 4 + K::quad(q)) * 16u;
         f32x4 wp[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) wp[n] = stream_ld(lds0 + wpo + (unsigned)((ch * NT + n) * 64 + lane) * 16u);
         f32x4 d[kStreamMT];
 #pragma unroll
         for (int m = 0; m < kStreamMT; ++m) d[m] = kStreamZero;
+        const unsigned dwb = lds0 + dww + qoff;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             f32x4 dw[3], xv[5];
+            const unsigned xb = rowb[dy] + qoff;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) dw[dx] = stream_ld(lds0 + dww + (unsigned)((dy * 3 + dx) * in_quads) * 16u + qoff);
+            for (int dx = 0; dx < 3; ++dx) dw[dx] = STREAM_ABL == 4 ? f32x4{1.0f, 2.0f, 3.0f, (float)dx} : stream_ld(dwb + (unsigned)((dy * 3 + dx) * QUADS) * 16u);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) xv[k] = stream_ld(rowb[dy] + (unsigned)k * in_px + qoff);
+            for (int k = 0; k < 5; ++k) xv[k] = STREAM_ABL == 3 ? f32x4{(float)k, (float)lane, 1.0f, 2.0f} : stream_ld(xb + (unsigned)k * PX);
 #pragma unroll
             for (int m = 0; m < kStreamMT; ++m)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) d[m] += dw[dx] * xv[m + dx];
+                for (int dx = 0; dx < 3; ++dx) {
+                    if (STREAM_ABL == 2) { if (dx == 1) d[m] += xv[m + dx] + dw[dx]; }
+                    else d[m] += dw[dx] * xv[m + dx];
+                }
             asm volatile("" ::: "memory");      // keeps the next row's 8 reads behind these FMAs: 32 VGPRs, not 96
         }
-        if (!qv) {
+        // (lanes of a missing quad hold the depthwise of a real one: finite, times zero filter rows)
 #pragma unroll
-            for (int m = 0; m < kStreamMT; ++m) d[m] = kStreamZero;
-        }
+        for (int s = 0; s < K::STEPS; ++s)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int m = 0; m < kStreamMT; ++m) {
+                const float bv = K::pick(d[m], s, q);
 #pragma unroll
-            for (int m = 0; m < kStreamMT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[n][s], d[m][s], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) {
+                    if (STREAM_ABL == 1) { if (s == 0) acc[m][n] += d[m] * wp[n]; }
+                    else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[n][s], bv, acc[m][n], 0, 0, 0);
+                }
+            }
     });
 }
 
 // ---- CNN2 .. CNNL, B2: depthwise 3x3 from the predecessor's ring -> pointwise GEMM -> bias, PReLU -----------------
-// CH = 16-channel chunks of the input, NT = 16-channel tiles of the output (compile time: no branches between the MFMAs)
-template <int CH, int NT>
+// QUADS = channel quads of the input, NT = 16-channel tiles of the output (compile time: no branches between the MFMAs)
+template <int QUADS, int NT>
 __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const StreamConv& c, unsigned lds0, int j0, int rows, int T, int lane) {
     const int j = lane & 15, q = lane >> 4;
-    const unsigned in_px = (unsigned)c.in.units * 16u, in_row = (unsigned)kStreamRowPx * in_px;
+    constexpr unsigned in_px = (unsigned)(QUADS | 1) * 16u, in_row = (unsigned)kStreamRowPx * in_px;
     StreamCursor cur;
     for (int t = 0; t < T; ++t) {
         const int g = t - c.lag;
@@ -225,26 +253,39 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
         for (int m = 0; m < kStreamMT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[m][n] = kStreamZero;
-        if (live) {
+        if (live && STREAM_ABL != 5 && STREAM_ABL != 8) {
             const StreamRow ri = stream_row(a, j0, cur, g);
             if (!ri.zero) {
                 unsigned rowb[3];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + c.in.off + (unsigned)((g + 2 * c.in.slots - 1 + dy) % c.in.slots) * in_row + (unsigned)(3 * j) * in_px;   // rows g-1, g, g+1
-                stream_dw_pw<CH, NT>(acc, lds0, rowb, in_px, c.in.quads, c.dww, c.wp, q, lane);
-            }
+                stream_dw_pw<QUADS, NT>(acc, lds0, rowb, c.dww, c.wp, q, lane);
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const f32x4 bs = stream_ld(lds0 + c.ba + (unsigned)(n * 4 + q) * 16u);
-                const f32x4 al = stream_ld(lds0 + c.ba + 128u + (unsigned)(n * 4 + q) * 16u);
+                for (int n = 0; n < NT; ++n) {
+                    const f32x4 bs = stream_ld(lds0 + c.ba + (unsigned)(n * 4 + q) * 16u);
+                    const f32x4 al = stream_ld(lds0 + c.ba + 128u + (unsigned)(n * 4 + q) * 16u);
 #pragma unroll
-                for (int m = 0; m < kStreamMT; ++m) {
-                    const int cx = ri.sx + 3 * j + m;
-                    const bool ok = !ri.zero && cx >= 0 && cx < a.W;
-                    const f32x4 r = stream_prelu(acc[m][n], bs, al);
-                    acc[m][n] = ok ? r : kStreamZero;
-                    if (c.to_global && ri.store && cx >= ri.ux0 && cx < ri.ux1 && n * 4 + q < c.out.quads)
-                        *reinterpret_cast<f32x4*>(a.out + (((size_t)ri.img * a.H + ri.r) * a.W + cx) * a.out_stride + (n * 4 + q) * 4) = acc[m][n];
+                    for (int m = 0; m < kStreamMT; ++m) acc[m][n] = stream_prelu(acc[m][n], bs, al);
+                }
+                if (ri.sx < 0 || ri.sx + kStreamPX > a.W) {          // the strip sticks out of the image: SAME padding is zero
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) {
+                        const int cx = ri.sx + 3 * j + m;
+                        if (cx < 0 || cx >= a.W) {
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) acc[m][n] = kStreamZero;
+                        }
+                    }
+                }
+                if (c.to_global && ri.store) {
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) {
+                        const int cx = ri.sx + 3 * j + m;
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            if (cx >= ri.ux0 && cx < ri.ux1 && n * 4 + q < c.out.quads)
+                                *reinterpret_cast<f32x4*>(a.out + (((size_t)ri.img * a.H + ri.r) * a.W + cx) * a.out_stride + (n * 4 + q) * 4) = acc[m][n];
+                    }
                 }
             }
         }
@@ -286,7 +327,7 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
         const int g = t + 1 - 2 * l;
         const bool live = g >= 0 && g < rows;
         const bool last = l == L;
-        if (live) {
+        if (live && STREAM_ABL != 6 && STREAM_ABL != 8) {
             const StreamNinSrc& s = a.nin[l - 1];
             auto body = [&](auto p_) DCSCN_INL {
                 constexpr int p = decltype(p_)::value;
@@ -295,23 +336,36 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
                     const unsigned rowb = lds0 + s.ring.off + ((unsigned)(g % 3) * kStreamRowPx + 3 * j + 1) * (unsigned)s.ring.units * 16u;
 #pragma unroll 1
                     for (int ch = 0; ch < s.chunks; ++ch) {
-                        const int quad = ch * 4 + q;
-                        const bool qv = quad < s.ring.quads;
-                        const unsigned qoff = (unsigned)(qv ? quad : 0) * 16u;
+                        // StreamChunk<ql> with a run-time ql (one code path: this role is short of registers, not of VALU slots)
+                        const int ql = ch == s.chunks - 1 ? s.last_ql : 4;
+                        const int steps = ql >= 3 ? 4 : ql;
+                        const int cq = ql >= 3 ? min(q, ql - 1) : ql == 2 ? (q & 1) : 0;
+                        const int eoff = ql == 2 ? 2 * (q >> 1) : ql == 1 ? q : 0;
+                        const unsigned qoff = (unsigned)(ch * 4 + cq) * 16u;
                         const f32x4 w0 = stream_ld(lds0 + s.w + (unsigned)((ch * 2 + 0) * 64 + lane) * 16u);
                         const f32x4 w1 = stream_ld(lds0 + s.w + (unsigned)((ch * 2 + 1) * 64 + lane) * 16u);
                         f32x4 xv[kStreamMT];
 #pragma unroll
-                        for (int m = 0; m < kStreamMT; ++m) {
-                            xv[m] = stream_ld(rowb + (unsigned)(m * s.ring.units) * 16u + qoff);
-                            if (!qv) xv[m] = kStreamZero;
+                        for (int m = 0; m < kStreamMT; ++m) xv[m] = stream_ld(rowb + (unsigned)(m * s.ring.units) * 16u + qoff);
+                        if (ql <= 2) {
+                            // element eoff + k feeds k-step k: rotate the float4 by eoff
+#pragma unroll
+                            for (int m = 0; m < kStreamMT; ++m) {
+                                const f32x4 x = xv[m];
+                                const float e0 = eoff == 0 ? x.x : eoff == 1 ? x.y : eoff == 2 ? x.z : x.w;
+                                const float e1 = eoff == 0 ? x.y : x.w;           // only ql == 2 has a second k-step (eoff 0 or 2)
+                                xv[m].x = e0;
+                                xv[m].y = e1;
+                            }
                         }
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
+                            if (k < steps) {
 #pragma unroll
-                            for (int m = 0; m < kStreamMT; ++m) {
-                                acc[p][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[k], xv[m][k], acc[p][m][0], 0, 0, 0);
-                                acc[p][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[k], xv[m][k], acc[p][m][1], 0, 0, 0);
+                                for (int m = 0; m < kStreamMT; ++m) {
+                                    acc[p][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[k], xv[m][k], acc[p][m][0], 0, 0, 0);
+                                    acc[p][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[k], xv[m][k], acc[p][m][1], 0, 0, 0);
+                                }
                             }
                     }
                 }
@@ -365,11 +419,18 @@ __global__ __launch_bounds__(1024) void feat_stream(const StreamArgs a) {
     if (wave == 0) stream_first_role(a, lds0, j0, rows, T, lane);
     else if (wave <= a.n_conv) {
         const StreamConv& c = a.conv[wave - 1];
-        const bool ch2 = c.in.quads > 4, nt2 = c.out.quads > 4;
-        if (ch2 && nt2) stream_conv_role<2, 2>(a, c, lds0, j0, rows, T, lane);
-        else if (ch2) stream_conv_role<2, 1>(a, c, lds0, j0, rows, T, lane);
-        else if (nt2) stream_conv_role<1, 2>(a, c, lds0, j0, rows, T, lane);
-        else stream_conv_role<1, 1>(a, c, lds0, j0, rows, T, lane);
+        // the instantiated (input quads, output tiles) pairs -- api.hip: stream_conv_supported
+        const bool nt2 = c.out.quads > 4;
+        switch (c.in.quads) {
+            case 1: stream_conv_role<1, 1>(a, c, lds0, j0, rows, T, lane); break;
+            case 2: stream_conv_role<2, 1>(a, c, lds0, j0, rows, T, lane); break;
+            case 3: stream_conv_role<3, 1>(a, c, lds0, j0, rows, T, lane); break;
+            case 4: stream_conv_role<4, 1>(a, c, lds0, j0, rows, T, lane); break;
+            case 5: stream_conv_role<5, 1>(a, c, lds0, j0, rows, T, lane); break;
+            case 6: stream_conv_role<6, 2>(a, c, lds0, j0, rows, T, lane); break;
+            case 7: stream_conv_role<7, 2>(a, c, lds0, j0, rows, T, lane); break;
+            default: if (nt2) stream_conv_role<8, 2>(a, c, lds0, j0, rows, T, lane); else stream_conv_role<8, 1>(a, c, lds0, j0, rows, T, lane); break;
+        }
     } else stream_nin_role(a, wave - 1 - a.n_conv, lds0, j0, rows, T, lane);
 }
 

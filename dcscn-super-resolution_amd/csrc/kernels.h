@@ -120,7 +120,7 @@ struct StreamNinSrc {     // one feature layer as a K-slice of A1 || B1
     StreamRing ring;
     int32_t chunks;       // 16-channel chunks
     int32_t w;            // LDS byte offset of [chunk][2 tiles][64 lanes] float4 (k-steps 0..3)
-    int32_t last_steps;   // k-steps of the last chunk that hold channels (1..4)
+    int32_t last_ql;      // valid channel quads of the last chunk (1..4): feat_stream.hpp StreamChunk
 };
 struct StreamArgs {
     const float* x;       // [N, H, W] luma

@@ -51,7 +51,7 @@ __device__ __forceinline__ void tail_load_role(const TailArgs& a, const StreamAr
             const int it = lane + 64 * i;
             const int px = it / a.in.quads, quad = it - px * a.in.quads;
             const int cx = ri.sx + px;
-            dst[i] = live && it < n_items && cx >= 0 && cx < a.W ? *reinterpret_cast<const f32x4*>(row + (size_t)cx * a.c2_stride + 4 * quad) : kStreamZero;
+            dst[i] = live && it < n_items && cx >= 0 && cx < a.W && STREAM_ABL != 10 && STREAM_ABL != 13 && STREAM_ABL != 14 ? *reinterpret_cast<const f32x4*>(row + (size_t)cx * a.c2_stride + 4 * quad) : kStreamZero;
         }
     };
     load_row(0, now);
@@ -74,10 +74,11 @@ __device__ __forceinline__ void tail_load_role(const TailArgs& a, const StreamAr
 }
 
 // ---- Up-PS, one sub-pixel phase ------------------------------------------------------------------------------------
+template <int QI>
 __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArgs& geo, int phase, unsigned lds0, int j0, int rows, int T, int lane) {
     const int j = lane & 15, q = lane >> 4;
     const int dy_o = phase >> 1, dx_o = phase & 1;
-    const unsigned in_px = (unsigned)a.in.units * 16u, in_row = (unsigned)kStreamRowPx * in_px;
+    constexpr unsigned in_px = (unsigned)(QI | 1) * 16u, in_row = (unsigned)kStreamRowPx * in_px;
     const unsigned u_px = (unsigned)a.u.units * 16u, u_row = (unsigned)kTailURowPx * u_px;
     StreamCursor cur;
     for (int t = 0; t < T; ++t) {
@@ -88,13 +89,13 @@ __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArg
         for (int m = 0; m < kStreamMT; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) acc[m][n] = kStreamZero;
-        if (live) {
+        if (live && STREAM_ABL != 11 && STREAM_ABL != 13 && STREAM_ABL != 14) {
             const StreamRow ri = stream_row(geo, j0, cur, g);
             if (!ri.zero) {
                 unsigned rowb[3];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + a.in.off + (unsigned)((g + 2 + dy) % 3) * in_row + (unsigned)(3 * j) * in_px;
-                stream_dw_pw<2, 2>(acc, lds0, rowb, in_px, a.in.quads, a.a_dww, a.a_wp + phase * (2 * 2 * 64 * 16), q, lane);
+                stream_dw_pw<QI, 2>(acc, lds0, rowb, a.a_dww, a.a_wp + phase * (2 * 2 * 64 * 16), q, lane);
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -122,9 +123,10 @@ __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArg
 }
 
 // ---- Up-PS2 on U row 2g + r2, pixels 48 * half .. + 47 ------------------------------------------------------------------
+template <int QU>
 __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArgs& geo, int r2, int half, unsigned lds0, int j0, int rows, int T, int lane) {
     const int j = lane & 15, q = lane >> 4;
-    const unsigned u_px = (unsigned)a.u.units * 16u, u_row = (unsigned)kTailURowPx * u_px;
+    constexpr unsigned u_px = (unsigned)(QU | 1) * 16u, u_row = (unsigned)kTailURowPx * u_px;
     StreamCursor cur;
     for (int t = 0; t < T; ++t) {
         const int g = t - 4;
@@ -132,7 +134,7 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
         f32x4 acc[kStreamMT][1];
 #pragma unroll
         for (int m = 0; m < kStreamMT; ++m) acc[m][0] = kStreamZero;
-        if (live) {
+        if (live && STREAM_ABL != 12 && STREAM_ABL != 13 && STREAM_ABL != 14) {
             const StreamRow ri = stream_row(geo, j0, cur, g);
             if (!ri.zero) {
                 const int ur = 2 * g + r2;
@@ -140,7 +142,7 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
                     rowb[dy] = lds0 + a.u.off + (unsigned)((ur - 1 + dy + kTailUSlots) % kTailUSlots) * u_row + (unsigned)(kStreamPX * half + 3 * j) * u_px;
-                stream_dw_pw<2, 1>(acc, lds0, rowb, u_px, a.u.quads, a.b_dww, a.b_wp, q, lane);
+                stream_dw_pw<QU, 1>(acc, lds0, rowb, a.b_dww, a.b_wp, q, lane);
             }
             const f32x4 bs = stream_ld(lds0 + a.b_bias);
 #pragma unroll
@@ -173,25 +175,34 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
 // ---- R-CNN1 + residual on HR rows 4g + 2c + {0, 1} -----------------------------------------------------------------------
 __device__ __forceinline__ void tail_rec_role(const TailArgs& a, const StreamArgs& geo, int c, unsigned lds0, int j0, int rows, int T, int lane) {
     typedef const __attribute__((address_space(3))) float* lds_f1;
-    StreamCursor cur;
+    StreamCursor cur, pcur;
     const int W4 = 4 * a.W;
+    // the bicubic pixels of the NEXT step's rows are fetched one step ahead (a global load issued and consumed inside
+    // one step put its whole latency, ~4000 cycles, on the step's critical path)
+    float res[2][3], nres[2][3];
+    auto fetch = [&](int gs, float (&dst)[2][3]) DCSCN_INL {
+        const bool in = gs >= 0 && gs < rows;
+        const StreamRow ri = stream_row(geo, j0, pcur, in ? gs : 0);
+        const int cx0 = 4 * ri.sx + 3 * lane;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int cx = cx0 + k;
+                const bool ok = in && ri.store && cx >= 4 * ri.ux0 && cx < 4 * ri.ux1 && STREAM_ABL != 9 && STREAM_ABL != 13;
+                dst[e][k] = ok ? a.x2[((size_t)ri.img * 4 * a.H + 4 * ri.r + 2 * c + e) * W4 + cx] : 0.0f;
+            }
+    };
+    fetch(-6, res);
     for (int t = 0; t < T; ++t) {
         const int g = t - 6;
         const bool live = g >= 0 && g < rows;
+        fetch(g + 1, nres);
         if (live) {
             const StreamRow ri = stream_row(geo, j0, cur, g);
-            if (ri.store) {
+            if (ri.store && STREAM_ABL != 9 && STREAM_ABL != 13) {
                 const int vr0 = 4 * g + 2 * c;                  // first output row in V-row numbering
                 const int cx0 = 4 * ri.sx + 3 * lane;           // first of the lane's three HR columns
-                float res[2][3];
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int cx = cx0 + k;
-                        const bool ok = cx >= 4 * ri.ux0 && cx < 4 * ri.ux1;
-                        res[e][k] = ok ? a.x2[((size_t)ri.img * 4 * a.H + 4 * ri.r + 2 * c + e) * W4 + cx] : 0.0f;
-                    }
                 float v[4][5];
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
@@ -216,6 +227,10 @@ __device__ __forceinline__ void tail_rec_role(const TailArgs& a, const StreamArg
         }
         stream_barrier();
         stream_barrier();
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) res[e][k] = nres[e][k];
     }
 }
 
@@ -237,8 +252,22 @@ __global__ __launch_bounds__(704) void tail_stream(const TailArgs a) {
     const int rows = (j1 - j0) * (a.rows_c + 1);
     const int T = rows + 6;
     if (wave == 0) tail_load_role(a, geo, lds0, j0, rows, T, lane);
-    else if (wave <= 4) tail_up1_role(a, geo, wave - 1, lds0, j0, rows, T, lane);
-    else if (wave <= 8) tail_up2_role(a, geo, (wave - 5) >> 1, (wave - 5) & 1, lds0, j0, rows, T, lane);
+    else if (wave <= 4) {
+        switch (a.in.quads) {
+            case 5: tail_up1_role<5>(a, geo, wave - 1, lds0, j0, rows, T, lane); break;
+            case 6: tail_up1_role<6>(a, geo, wave - 1, lds0, j0, rows, T, lane); break;
+            case 7: tail_up1_role<7>(a, geo, wave - 1, lds0, j0, rows, T, lane); break;
+            default: tail_up1_role<8>(a, geo, wave - 1, lds0, j0, rows, T, lane); break;
+        }
+    } else if (wave <= 8) {
+        const int r2 = (wave - 5) >> 1, half = (wave - 5) & 1;
+        switch (a.u.quads) {
+            case 5: tail_up2_role<5>(a, geo, r2, half, lds0, j0, rows, T, lane); break;
+            case 6: tail_up2_role<6>(a, geo, r2, half, lds0, j0, rows, T, lane); break;
+            case 7: tail_up2_role<7>(a, geo, r2, half, lds0, j0, rows, T, lane); break;
+            default: tail_up2_role<8>(a, geo, r2, half, lds0, j0, rows, T, lane); break;
+        }
+    }
     else tail_rec_role(a, geo, wave - 9, lds0, j0, rows, T, lane);
 }
 
