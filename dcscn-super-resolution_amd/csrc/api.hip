@@ -1070,7 +1070,25 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.n_jobs = (int)(cols * a.n_blocks);
         a.jobs_per_wg = (a.n_jobs + 255) / 256;
         const int grid = (a.n_jobs + a.jobs_per_wg - 1) / a.jobs_per_wg;
+        static long long* dbg = nullptr;
+        if (getenv("DCSCN_STREAM_DBG")) {
+            if (!dbg) HIP_TRY(h, hipMalloc((void**)&dbg, 16 * 64 * 4 * sizeof(long long)));
+            HIP_TRY(h, hipMemsetAsync(dbg, 0, 16 * 64 * 4 * sizeof(long long), stream));
+            a.dbg = dbg;
+        }
         HIP_TRY(h, stream_launch(a, grid, stream));
+        if (a.dbg) {
+            std::vector<long long> host(16 * 64 * 4);
+            HIP_TRY(h, hipStreamSynchronize(stream));
+            HIP_TRY(h, hipMemcpy(host.data(), dbg, host.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            FILE* f = fopen(getenv("DCSCN_STREAM_DBG"), "w");
+            if (f) {
+                for (int w = 0; w < 2 * a.L + 1; ++w)
+                    for (int t = 0; t < 64; ++t)
+                        fprintf(f, "%d %d %d %lld %lld %lld %lld\n", w, (int)a.role[w], t, host[(w * 64 + t) * 4], host[(w * 64 + t) * 4 + 1], host[(w * 64 + t) * 4 + 2], host[(w * 64 + t) * 4 + 3]);
+                fclose(f);
+            }
+        }
         return DCSCN_OK;
     }
     if (op.kind == OP_DW) {
@@ -1798,7 +1816,7 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
     auto bias_alpha = [&](const Op& o, const ColSeg& sg, int dst, size_t base) {
         for (int co = 0; co < sg.cout; ++co) {
             blob[base + dst + co] = sg.b >= 0 ? tens(sg.b)[sg.col0 + co] : 0.0f;
-            blob[base + 32 + dst + co] = sg.alpha >= 0 ? tens(sg.alpha)[sg.col0 + co] : o.const_alpha;
+            blob[base + 32 + dst + co] = (sg.alpha >= 0 ? tens(sg.alpha)[sg.col0 + co] : o.const_alpha) - 1.0f;     // stream_prelu wants alpha - 1
         }
     };
     // --- pointwise filters [chunk][tile][lane] float4, bias, slope of the streamed convs ---
@@ -1838,6 +1856,33 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
     a.ldsw_src = 0;
     a.ldsw_bytes = lds - a.ring_bytes;
     if ((size_t)a.ldsw_bytes != blob.size() * sizeof(float)) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat_stream LDS image size");
+    {
+        // wave -> role: wave w runs on SIMD w & 3 and the matrix pipe is per SIMD, so spread the MFMA counts (heaviest first,
+        // always onto the least loaded SIMD that still has a wave left)
+        auto ksteps = [](int quads) { const int ch = (quads + 3) / 4, ql = quads - 4 * (ch - 1); return 4 * (ch - 1) + (ql >= 3 ? 4 : ql); };
+        std::vector<std::pair<int, int>> roles;           // (MFMAs per row, role code)
+        roles.push_back({0, 0});
+        int nin_total = 0;
+        for (int i = 0; i < L; ++i) {
+            roles.push_back({3 * ((a.conv[i].out.quads + 3) / 4) * ksteps(a.conv[i].in.quads), 1 + i});
+            nin_total += 6 * ksteps(fr[i].quads);
+        }
+        for (int i = 0; i < L; ++i) roles.push_back({nin_total / L, 16 + i});
+        std::sort(roles.begin(), roles.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
+        const int waves = 2 * L + 1;
+        int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+        for (int w = 0; w < 16; ++w) a.role[w] = 0;
+        for (const auto& r : roles) {
+            int best = -1;
+            for (int sd = 0; sd < 4; ++sd) {
+                if (sd + 4 * used[sd] >= waves) continue;
+                if (best < 0 || load[sd] < load[best]) best = sd;
+            }
+            a.role[best + 4 * used[best]] = (int8_t)r.second;
+            used[best] += 1;
+            load[best] += r.first;
+        }
+    }
     if (lds > 160 * 1024) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat_stream needs %d bytes of LDS", lds);
 
     // --- CNN1 (global, read once into registers): depthwise[9] (+3 pad), pointwise[32], bias[32], slope[32] ---

@@ -41,6 +41,17 @@ typedef const __attribute__((address_space(3))) f32x4* stream_lds_rd;
 typedef __attribute__((address_space(3))) f32x4* stream_lds_wr;
 
 __device__ __forceinline__ void stream_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifdef STREAM_DBG
+// timing probe: workgroup 0 records the shader clock at four points of steps 64..127 per wave
+#define STREAM_STAMP(a, t, k)                                                                                     \
+    do {                                                                                                          \
+        if ((a).dbg && blockIdx.x == 0 && (t) >= 64 && (t) < 128 && (threadIdx.x & 63) == 0)                        \
+            (a).dbg[((threadIdx.x >> 6) * 64 + ((t) - 64)) * 4 + (k)] = clock64();                                 \
+    } while (0)
+#else
+#define STREAM_STAMP(a, t, k) do { } while (0)
+#endif
 __device__ __forceinline__ f32x4 stream_ld(unsigned addr) { return *(stream_lds_rd)(uintptr_t)addr; }
 __device__ __forceinline__ void stream_st(unsigned addr, f32x4 v) { *(stream_lds_wr)(uintptr_t)addr = v; }
 
@@ -88,13 +99,16 @@ __device__ __forceinline__ StreamRow stream_row(const StreamArgs& a, int j0, Str
     return o;
 }
 
-__device__ __forceinline__ f32x4 stream_prelu(f32x4 v, f32x4 b, f32x4 al) {
+// bias + PReLU as v + (alpha - 1) * min(v, 0): 4 v_min + 2 v_pk_fma instead of 4 compares, 4 selects and 2 multiplies
+// (`am1` = alpha - 1, precomputed on the host; differs from alpha * v by one rounding of a product that is then added to v)
+__device__ __forceinline__ f32x4 stream_prelu(f32x4 v, f32x4 b, f32x4 am1) {
     v += b;
-    v.x = v.x > 0.0f ? v.x : al.x * v.x;
-    v.y = v.y > 0.0f ? v.y : al.y * v.y;
-    v.z = v.z > 0.0f ? v.z : al.z * v.z;
-    v.w = v.w > 0.0f ? v.w : al.w * v.w;
-    return v;
+    f32x4 n;
+    n.x = fminf(v.x, 0.0f);
+    n.y = fminf(v.y, 0.0f);
+    n.z = fminf(v.z, 0.0f);
+    n.w = fminf(v.w, 0.0f);
+    return v + am1 * n;
 }
 
 constexpr f32x4 kStreamZero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -132,6 +146,7 @@ __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned 
     load_row(0, xw[2]);
     load_row(1, xw[3]);
     for (int t = 0; t < T; ++t) {
+        STREAM_STAMP(a, t, 0);
         const int g = t;
 #pragma unroll
         for (int s = 0; s < 3; ++s)
@@ -154,7 +169,9 @@ __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned 
                 ok[m] = !ri.zero && cx >= 0 && cx < a.W;
             }
         }
+        STREAM_STAMP(a, t, 1);
         stream_barrier();
+        STREAM_STAMP(a, t, 2);
         if (live) {
             const unsigned slot = (unsigned)(g % 3);
 #pragma unroll
@@ -167,6 +184,7 @@ __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned 
                                   ok[m] ? r : kStreamZero);
                     }
         }
+        STREAM_STAMP(a, t, 3);
         stream_barrier();
     }
 }
@@ -206,23 +224,37 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[kStreamMT][NT], unsign
 #pragma unroll
         for (int m = 0; m < kStreamMT; ++m) d[m] = kStreamZero;
         const unsigned dwb = lds0 + dww + qoff;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            f32x4 dw[3], xv[5];
+        // rows are double buffered: the reads of row dy + 1 are in flight while row dy is multiplied (the compiler
+        // barriers keep it from hoisting all three rows -- 96 VGPRs -- or none)
+        f32x4 dw[2][3], xv[2][5];
+        auto fetch = [&](auto dy_, auto b_) DCSCN_INL {
+            constexpr int dy = decltype(dy_)::value, b = decltype(b_)::value;
             const unsigned xb = rowb[dy] + qoff;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) dw[dx] = STREAM_ABL == 4 ? f32x4{1.0f, 2.0f, 3.0f, (float)dx} : stream_ld(dwb + (unsigned)((dy * 3 + dx) * QUADS) * 16u);
+            for (int dx = 0; dx < 3; ++dx) dw[b][dx] = STREAM_ABL == 4 ? f32x4{1.0f, 2.0f, 3.0f, (float)dx} : stream_ld(dwb + (unsigned)((dy * 3 + dx) * QUADS) * 16u);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) xv[k] = STREAM_ABL == 3 ? f32x4{(float)k, (float)lane, 1.0f, 2.0f} : stream_ld(xb + (unsigned)k * PX);
+            for (int k = 0; k < 5; ++k) xv[b][k] = STREAM_ABL == 3 ? f32x4{(float)k, (float)lane, 1.0f, 2.0f} : stream_ld(xb + (unsigned)k * PX);
+        };
+        auto mult = [&](auto b_) DCSCN_INL {
+            constexpr int b = decltype(b_)::value;
 #pragma unroll
             for (int m = 0; m < kStreamMT; ++m)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    if (STREAM_ABL == 2) { if (dx == 1) d[m] += xv[m + dx] + dw[dx]; }
-                    else d[m] += dw[dx] * xv[m + dx];
+                    if (STREAM_ABL == 2) { if (dx == 1) d[m] += xv[b][m + dx] + dw[b][dx]; }
+                    else d[m] += dw[b][dx] * xv[b][m + dx];
                 }
-            asm volatile("" ::: "memory");      // keeps the next row's 8 reads behind these FMAs: 32 VGPRs, not 96
-        }
+            asm volatile("" ::: "memory");
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        fetch(I0{}, I0{});
+        fetch(I1{}, I1{});
+        mult(I0{});
+        fetch(I2{}, I0{});
+        mult(I1{});
+        mult(I0{});
         // (lanes of a missing quad hold the depthwise of a real one: finite, times zero filter rows)
 #pragma unroll
         for (int s = 0; s < K::STEPS; ++s)
@@ -246,6 +278,7 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
     constexpr unsigned in_px = (unsigned)(QUADS | 1) * 16u, in_row = (unsigned)kStreamRowPx * in_px;
     StreamCursor cur;
     for (int t = 0; t < T; ++t) {
+        STREAM_STAMP(a, t, 0);
         const int g = t - c.lag;
         const bool live = g >= 0 && g < rows;
         f32x4 acc[kStreamMT][NT];
@@ -289,7 +322,9 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
                 }
             }
         }
+        STREAM_STAMP(a, t, 1);
         stream_barrier();
+        STREAM_STAMP(a, t, 2);
         if (live && !c.to_global) {
             const unsigned slot = (unsigned)(g % 3);
 #pragma unroll
@@ -299,6 +334,7 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
                     if (n * 4 + q < c.out.quads)
                         stream_st(lds0 + c.out.off + ((slot * kStreamRowPx + 3 * j + m + 1) * c.out.units + n * 4 + q) * 16u, acc[m][n]);
         }
+        STREAM_STAMP(a, t, 3);
         stream_barrier();
     }
 }
@@ -316,6 +352,7 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
     StreamCursor cur[2];       // the wave alternates between an even and an odd row; each advances by 2L rows at a time
 
     for (int t = 0; t < T; ++t) {
+        STREAM_STAMP(a, t, 0);
         // (opaque per step: otherwise every lane-derived address of every branch is hoisted out of the loop and spilled)
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));
@@ -395,7 +432,10 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
             if (g & 1) body(std::integral_constant<int, 1>{});
             else body(std::integral_constant<int, 0>{});
         }
+        STREAM_STAMP(a, t, 1);
         stream_barrier();
+        STREAM_STAMP(a, t, 2);
+        STREAM_STAMP(a, t, 3);
         stream_barrier();
     }
 }
@@ -416,9 +456,10 @@ __global__ __launch_bounds__(1024) void feat_stream(const StreamArgs a) {
     const int j1 = min(a.n_jobs, j0 + a.jobs_per_wg);
     const int rows = (j1 - j0) * (a.rows_c + 1);
     const int T = rows + a.total_lag;
-    if (wave == 0) stream_first_role(a, lds0, j0, rows, T, lane);
-    else if (wave <= a.n_conv) {
-        const StreamConv& c = a.conv[wave - 1];
+    const int role = a.role[wave];
+    if (role == 0) stream_first_role(a, lds0, j0, rows, T, lane);
+    else if (role < 16) {
+        const StreamConv& c = a.conv[role - 1];
         // the instantiated (input quads, output tiles) pairs -- api.hip: stream_conv_supported
         const bool nt2 = c.out.quads > 4;
         switch (c.in.quads) {
@@ -431,7 +472,7 @@ __global__ __launch_bounds__(1024) void feat_stream(const StreamArgs a) {
             case 7: stream_conv_role<7, 2>(a, c, lds0, j0, rows, T, lane); break;
             default: if (nt2) stream_conv_role<8, 2>(a, c, lds0, j0, rows, T, lane); else stream_conv_role<8, 1>(a, c, lds0, j0, rows, T, lane); break;
         }
-    } else stream_nin_role(a, wave - 1 - a.n_conv, lds0, j0, rows, T, lane);
+    } else stream_nin_role(a, role - 16, lds0, j0, rows, T, lane);
 }
 
 }  // namespace dcscn

@@ -132,6 +132,8 @@ struct StreamArgs {
     int32_t n_blocks, useful_h, rows_c;    // row block b computes rows_c rows from b * useful_h - halo (0 when n_blocks == 1)
     int32_t n_jobs, jobs_per_wg;
     int32_t L, n_conv, total_lag;
+    long long* dbg;                        // timing probe (STREAM_DBG builds, tools/stream_abl.sh): [wave][step][4] shader clocks of workgroup 0
+    int8_t role[16];                       // wave -> 0: CNN1, 1 .. n_conv: conv[role - 1], 16 + i: A1 || B1 row slot i (balanced over the 4 SIMDs)
     int32_t ring_bytes, ldsw_bytes, ldsw_src;   // LDS image: [0, ring_bytes) zero, then ldsw_bytes copied from blob + ldsw_src
     int32_t first_w;                       // blob offset of CNN1: depthwise[9 (+3)], pointwise[32], bias[32], slope[32]
     StreamRing first_out;
