@@ -1627,7 +1627,9 @@ void fuse_tail_stream(dcscn_ctx* h) {
     const Op& rc = h->ops[n - 1];
     auto is_up = [](const Op& o) { return o.kind == OP_CONV && o.dwk == 3 && o.ks == 1 && o.segs.size() == 1 && o.act == ACT_NONE && o.ps == 2 && o.tconv_s == 0 && o.fold_s == 0; };
     if (!is_up(u1) || !is_up(u2) || u1.res != 1 || u2.res != 2) return;
-    if (u1.cin <= 16 || u1.cin > 32 || u1.cin % 4 != 0 || u1.ps_c <= 16 || u1.ps_c > 32 || u1.ps_c % 4 != 0) return;
+    // tail_stream is instantiated for 8 channel quads in and out of Up-PS (every shipped separable checkpoint: A1 || B2 = 32
+    // channels, pixel shuffler to 32); other widths keep the layer-by-layer tail
+    if (u1.cin != 32 || u1.ps_c != 32) return;
     if (u2.cin != u1.ps_c || u2.ps_c != 1 || u2.in_buf != u1.out_buf[0]) return;
     for (int i = 0; i < u1.cin; ++i)
         if (u1.chan_map[i] != i) return;
@@ -1683,24 +1685,27 @@ int pack_tail_stream(dcscn_ctx* h, Op& op) {
     }
     a.a_wp = lds;
     {
-        const size_t base = region((size_t)4 * 2 * 2 * 64 * 4);
+        // [chunk][channel tile 0..7][lane] float4 over the 4C conv channels (tile = 2 * phase + half when C > 16)
+        const size_t base = region((size_t)2 * 8 * 64 * 4);
         const ColSeg& sg = u1.segs[0];
         const std::vector<float>& pw = tens(sg.w);                    // [1, 1, cin, 4C]: column phase * C + c
-        for (int ph = 0; ph < 4; ++ph)
-            for (int ch = 0; ch < 2; ++ch)
-                for (int n = 0; n < 2; ++n)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int st = 0; st < 4; ++st) {
-                            const int ci = stream_chunk_channel(cin / 4, ch, lane >> 4, st), cc = 16 * n + (lane & 15);
-                            if (ci >= 0 && ci < cin && cc < C) blob[base + ((((size_t)ph * 2 + ch) * 2 + n) * 64 + lane) * 4 + st] = pw[(size_t)ci * 4 * C + ph * C + cc];
-                        }
+        const int tiles = C > 16 ? 2 : 1;
+        for (int ch = 0; ch < 2; ++ch)
+            for (int n = 0; n < 8; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int st = 0; st < 4; ++st) {
+                        const int ci = stream_chunk_channel(cin / 4, ch, lane >> 4, st);
+                        const int ph = n / tiles, cc = 16 * (n % tiles) + (lane & 15);
+                        if (ci >= 0 && ci < cin && ph < 4 && cc < C) blob[base + (((size_t)ch * 8 + n) * 64 + lane) * 4 + st] = pw[(size_t)ci * 4 * C + ph * C + cc];
+                    }
     }
     a.a_bias = lds;
     {
-        const size_t base = region(4 * 32);
+        const size_t base = region(8 * 16);                           // [channel tile][16]
         const ColSeg& sg = u1.segs[0];
+        const int tiles = C > 16 ? 2 : 1;
         for (int ph = 0; ph < 4; ++ph)
-            for (int cc = 0; cc < C; ++cc) blob[base + ph * 32 + cc] = sg.b >= 0 ? tens(sg.b)[ph * C + cc] : 0.0f;
+            for (int cc = 0; cc < C; ++cc) blob[base + (ph * tiles + cc / 16) * 16 + cc % 16] = sg.b >= 0 ? tens(sg.b)[ph * C + cc] : 0.0f;
     }
     // Up-PS2
     a.b_dww = lds;

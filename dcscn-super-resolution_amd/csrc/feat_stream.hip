@@ -10,7 +10,7 @@ void stream_init_kernels() {
 
 hipError_t tail_launch(const TailArgs& a, int grid, hipStream_t stream) {
     const size_t lds = (size_t)a.ring_bytes + a.ldsw_bytes;
-    hipLaunchKernelGGL(tail_stream, dim3(grid), dim3(704), lds, stream, a);
+    hipLaunchKernelGGL(tail_stream, dim3(grid), dim3(640), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -208,8 +208,8 @@ template <int QL> struct StreamChunk {
 // (row dy, the lane's first window pixel, quad 0); the lane's three pixels are window positions 0..2, 1..3, 2..4.
 // acc[m][n] += sum over chunks / k-steps of pointwise[n] x depthwise(pixel m).  QUADS = channel quads of the input ring
 // (compile time: every LDS offset below is an immediate).
-template <int QUADS, int NT>
-__device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[kStreamMT][NT], unsigned lds0, const unsigned (&rowb)[3], int dww, int wpo, int q, int lane) {
+template <int QUADS, int NT, int MT = kStreamMT>
+__device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], unsigned lds0, const unsigned (&rowb)[3], int dww, int wpo, int q, int lane) {
     constexpr int CH = (QUADS + 3) / 4;
     constexpr unsigned PX = (unsigned)(QUADS | 1) * 16u;
     static_for<0, CH>([&](auto ch_) DCSCN_INL {
@@ -220,25 +220,25 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[kStreamMT][NT], unsign
         f32x4 wp[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) wp[n] = stream_ld(lds0 + wpo + (unsigned)((ch * NT + n) * 64 + lane) * 16u);
-        f32x4 d[kStreamMT];
+        f32x4 d[MT];
 #pragma unroll
-        for (int m = 0; m < kStreamMT; ++m) d[m] = kStreamZero;
+        for (int m = 0; m < MT; ++m) d[m] = kStreamZero;
         const unsigned dwb = lds0 + dww + qoff;
         // rows are double buffered: the reads of row dy + 1 are in flight while row dy is multiplied (the compiler
         // barriers keep it from hoisting all three rows -- 96 VGPRs -- or none)
-        f32x4 dw[2][3], xv[2][5];
+        f32x4 dw[2][3], xv[2][MT + 2];
         auto fetch = [&](auto dy_, auto b_) DCSCN_INL {
             constexpr int dy = decltype(dy_)::value, b = decltype(b_)::value;
             const unsigned xb = rowb[dy] + qoff;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) dw[b][dx] = STREAM_ABL == 4 ? f32x4{1.0f, 2.0f, 3.0f, (float)dx} : stream_ld(dwb + (unsigned)((dy * 3 + dx) * QUADS) * 16u);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) xv[b][k] = STREAM_ABL == 3 ? f32x4{(float)k, (float)lane, 1.0f, 2.0f} : stream_ld(xb + (unsigned)k * PX);
+            for (int k = 0; k < MT + 2; ++k) xv[b][k] = STREAM_ABL == 3 ? f32x4{(float)k, (float)lane, 1.0f, 2.0f} : stream_ld(xb + (unsigned)k * PX);
         };
         auto mult = [&](auto b_) DCSCN_INL {
             constexpr int b = decltype(b_)::value;
 #pragma unroll
-            for (int m = 0; m < kStreamMT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     if (STREAM_ABL == 2) { if (dx == 1) d[m] += xv[b][m + dx] + dw[b][dx]; }
@@ -259,7 +259,7 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[kStreamMT][NT], unsign
 #pragma unroll
         for (int s = 0; s < K::STEPS; ++s)
 #pragma unroll
-            for (int m = 0; m < kStreamMT; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 const float bv = K::pick(d[m], s, q);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {

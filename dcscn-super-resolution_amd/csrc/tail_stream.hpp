@@ -8,12 +8,12 @@
 // barrier, jobs streamed back to back behind one zero row), with these roles:
 //
 //   wave 0        loads Concat2 row t+1 into registers while row t waits for its write phase -> IN ring (3 rows)
-//   waves 1..4    Up-PS, one sub-pixel phase (dy, dx) each: depthwise from IN, pointwise C -> C of that phase (MFMA), bias
-//                 -> row 2g+dy, pixels 2x+dx of the U ring (6 rows of 96 pixels x C channels)
-//   waves 5..8    Up-PS2 for one of the two new U rows x one 48-pixel half: depthwise from U, pointwise C -> 4 (MFMA, one
+//   waves 1..3    Up-PS on 16 pixels each: depthwise from IN (one pixel per lane), pointwise C -> 4C (MFMA, 8 channel tiles),
+//                 bias -> depth_to_space -> rows 2g, 2g+1 of the U ring (6 rows of 96 pixels x C channels)
+//   waves 4..7    Up-PS2 for one of the two new U rows x one 48-pixel half: depthwise from U, pointwise C -> 4 (MFMA, one
 //                 tile of which 4 columns are real), bias -> depth_to_space -> 2 rows x 96 pixels of the V ring (1 channel,
 //                 12 rows of 192 pixels)
-//   waves 9..10   R-CNN1 on two of the four new HR rows each: 3x3 on V, the pointwise scalar, + x2 -> y (global)
+//   waves 8..9    R-CNN1 on two of the four new HR rows each: 3x3 on V, the pointwise scalar, + x2 -> y (global)
 //
 // Lags: Up-PS runs 2 LR rows behind the loader, Up-PS2 2 behind Up-PS, R-CNN1 2 behind Up-PS2.
 #pragma once
@@ -73,50 +73,49 @@ __device__ __forceinline__ void tail_load_role(const TailArgs& a, const StreamAr
     }
 }
 
-// ---- Up-PS, one sub-pixel phase ------------------------------------------------------------------------------------
+// ---- Up-PS on 16 pixels, all four sub-pixel phases ------------------------------------------------------------------------
+// (splitting by phase instead would make four waves repeat the same depthwise; here a lane owns ONE pixel, its window is 3
+// reads per row, and the wave runs the whole [4C x C] pointwise: 8 channel tiles of accumulators)
 template <int QI>
-__device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArgs& geo, int phase, unsigned lds0, int j0, int rows, int T, int lane) {
+__device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArgs& geo, int seg, unsigned lds0, int j0, int rows, int T, int lane) {
     const int j = lane & 15, q = lane >> 4;
-    const int dy_o = phase >> 1, dx_o = phase & 1;
     constexpr unsigned in_px = (unsigned)(QI | 1) * 16u, in_row = (unsigned)kStreamRowPx * in_px;
     const unsigned u_px = (unsigned)a.u.units * 16u, u_row = (unsigned)kTailURowPx * u_px;
+    const int px = 16 * seg + j;
+    const int tiles = a.u.quads > 4 ? 2 : 1;          // channel tiles per phase
     StreamCursor cur;
     for (int t = 0; t < T; ++t) {
         const int g = t - 2;
         const bool live = g >= 0 && g < rows;
-        f32x4 acc[kStreamMT][2];
+        f32x4 acc[1][8];
 #pragma unroll
-        for (int m = 0; m < kStreamMT; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) acc[m][n] = kStreamZero;
+        for (int n = 0; n < 8; ++n) acc[0][n] = kStreamZero;
         if (live && STREAM_ABL != 11 && STREAM_ABL != 13 && STREAM_ABL != 14) {
             const StreamRow ri = stream_row(geo, j0, cur, g);
             if (!ri.zero) {
                 unsigned rowb[3];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + a.in.off + (unsigned)((g + 2 + dy) % 3) * in_row + (unsigned)(3 * j) * in_px;
-                stream_dw_pw<QI, 2>(acc, lds0, rowb, a.a_dww, a.a_wp + phase * (2 * 2 * 64 * 16), q, lane);
-            }
+                for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + a.in.off + (unsigned)((g + 2 + dy) % 3) * in_row + (unsigned)px * in_px;
+                stream_dw_pw<QI, 8, 1>(acc, lds0, rowb, a.a_dww, a.a_wp, q, lane);
+                const int cx = ri.sx + px;
+                const bool ok = cx >= 0 && cx < a.W;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const f32x4 bs = stream_ld(lds0 + a.a_bias + (unsigned)(phase * 8 + n * 4 + q) * 16u);
-#pragma unroll
-                for (int m = 0; m < kStreamMT; ++m) {
-                    const int cx = ri.sx + 3 * j + m;
-                    const bool ok = !ri.zero && cx >= 0 && cx < a.W;
-                    acc[m][n] = ok ? acc[m][n] + bs : kStreamZero;
+                for (int n = 0; n < 8; ++n) {
+                    const f32x4 bs = stream_ld(lds0 + a.a_bias + (unsigned)(n * 4 + q) * 16u);
+                    acc[0][n] = ok ? acc[0][n] + bs : kStreamZero;
                 }
             }
         }
         stream_barrier();
         if (live) {
-            const unsigned slot = (unsigned)((2 * g + dy_o) % kTailUSlots);
+            // conv channel 16n + 4q + e = phase * C + c (depth_to_space: phase = 2 dy + dx)
 #pragma unroll
-            for (int m = 0; m < kStreamMT; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    if (n * 4 + q < a.u.quads)
-                        stream_st(lds0 + a.u.off + slot * u_row + (unsigned)(2 * (3 * j + m) + dx_o + 1) * u_px + (unsigned)(n * 4 + q) * 16u, acc[m][n]);
+            for (int n = 0; n < 8; ++n) {
+                const int ph = tiles == 2 ? n >> 1 : n, quad = (tiles == 2 ? (n & 1) * 4 : 0) + q;
+                const unsigned slot = (unsigned)((2 * g + (ph >> 1)) % kTailUSlots);
+                if (quad < a.u.quads && ph < 4)
+                    stream_st(lds0 + a.u.off + slot * u_row + (unsigned)(2 * px + (ph & 1) + 1) * u_px + (unsigned)quad * 16u, acc[0][n]);
+            }
         }
         stream_barrier();
     }
@@ -234,7 +233,7 @@ __device__ __forceinline__ void tail_rec_role(const TailArgs& a, const StreamArg
     }
 }
 
-__global__ __launch_bounds__(704) void tail_stream(const TailArgs a) {
+__global__ __launch_bounds__(640) void tail_stream(const TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -252,23 +251,9 @@ __global__ __launch_bounds__(704) void tail_stream(const TailArgs a) {
     const int rows = (j1 - j0) * (a.rows_c + 1);
     const int T = rows + 6;
     if (wave == 0) tail_load_role(a, geo, lds0, j0, rows, T, lane);
-    else if (wave <= 4) {
-        switch (a.in.quads) {
-            case 5: tail_up1_role<5>(a, geo, wave - 1, lds0, j0, rows, T, lane); break;
-            case 6: tail_up1_role<6>(a, geo, wave - 1, lds0, j0, rows, T, lane); break;
-            case 7: tail_up1_role<7>(a, geo, wave - 1, lds0, j0, rows, T, lane); break;
-            default: tail_up1_role<8>(a, geo, wave - 1, lds0, j0, rows, T, lane); break;
-        }
-    } else if (wave <= 8) {
-        const int r2 = (wave - 5) >> 1, half = (wave - 5) & 1;
-        switch (a.u.quads) {
-            case 5: tail_up2_role<5>(a, geo, r2, half, lds0, j0, rows, T, lane); break;
-            case 6: tail_up2_role<6>(a, geo, r2, half, lds0, j0, rows, T, lane); break;
-            case 7: tail_up2_role<7>(a, geo, r2, half, lds0, j0, rows, T, lane); break;
-            default: tail_up2_role<8>(a, geo, r2, half, lds0, j0, rows, T, lane); break;
-        }
-    }
-    else tail_rec_role(a, geo, wave - 9, lds0, j0, rows, T, lane);
+    else if (wave <= 3) tail_up1_role<8>(a, geo, wave - 1, lds0, j0, rows, T, lane);      // instantiated for 32 -> 4 x 32 -> 4 channels (api.hip: fuse_tail_stream)
+    else if (wave <= 7) tail_up2_role<8>(a, geo, (wave - 4) >> 1, (wave - 4) & 1, lds0, j0, rows, T, lane);
+    else tail_rec_role(a, geo, wave - 8, lds0, j0, rows, T, lane);
 }
 
 }  // namespace dcscn

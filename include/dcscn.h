@@ -162,7 +162,12 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * "dense_features" (default 1; before dcscn_finalize only): every feature layer stores into its own dense NHWC buffer and
  * the 1x1 layer(s) that consume tf.concat (DCSCN.py:234) walk the list of buffers, instead of all layers sharing one
  * [n, h, w, sum C_i] tensor -- same bits, full cache lines.  0 = one concat tensor.  Ignored where a consumer of the
- * concat is not a 1x1 GEMM launch (cnn_size > 1 reconstruction without NIN). */
+ * concat is not a 1x1 GEMM launch (cnn_size > 1 reconstruction without NIN).
+ * "stream_features" / "stream_tail" (default 1; before dcscn_finalize only): the separable narrow nets (depthwise_separable,
+ * <= 7 feature layers of <= 32 filters, NIN of <= 32 channels) run CNN1 .. CNNL, A1 || B1 and B2 as ONE row-streamed launch
+ * with every intermediate tensor in LDS, and -- x4 models with a 32-channel pixel shuffler -- Up-PS, Up-PS2, the last
+ * reconstruction conv and the residual add as a second one.  0 = the layer-by-layer launches (same function, f32 results
+ * differ by accumulation order only). */
 int dcscn_set_option(dcscn_handle h, const char* key, int64_t value);
 
 /* Forward pass on host buffers: H2D, kernels, D2H, synchronous. */

@@ -415,3 +415,35 @@ def test_dense_feature_buffers_are_bit_identical_to_the_concat_tensor(oracle, na
             eng.load_weights(weights)
             outs.append(eng.forward(x, x2))
     assert outs[0].tobytes() == outs[1].tobytes()
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 48), (1, 61, 130), (1, 300, 70), (3, 20, 97)])
+def test_streamed_separable_net_matches_layer_by_layer(oracle, shape):
+    """feat_stream / tail_stream (options stream_features / stream_tail, default on) against the layer-by-layer launches of
+    the same library on the separable x4 net, with the last conv NOT attenuated and x2 = 0 (bare network branch): single
+    strip, column strips with halos (w > 48), row blocks with halos (tall single image), ragged widths.  Both paths are
+    f32; they differ by accumulation order only."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS["L7_F32to8_x4_DS"])
+    weights = oracle.synthetic_weights(cfg, seed=11)
+    last = "R-CNN%d" % cfg["reconstruct_layers"]              # the layer synthetic_weights scales by 0.01 (none when 0)
+    for k in list(weights):
+        if k.startswith(last + "/") and k.endswith(("conv_W", "pointwise_W")):
+            weights[k] = weights[k] * 100.0
+    n, h, w = shape
+    x, x2 = synthetic_batch(n, h, w, cfg["scale"], seed=h + w)
+    x2 = np.zeros_like(x2)
+    outs = {}
+    for mode in (1, 0):
+        with engine.Engine(cfg, device=0) as eng:
+            eng.set_option("stream_features", mode)
+            eng.set_option("stream_tail", mode)
+            eng.load_weights(weights)
+            kernels = [o["kernel"] for o in eng.ops()]
+            assert (kernels == ["feat_stream", "tail_stream"]) == (mode == 1), kernels
+            outs[mode] = eng.forward(x, x2).astype(np.float64)
+    scale = np.abs(outs[0]).max()
+    assert scale > 1.0
+    err = np.abs(outs[1] - outs[0]).max() / scale
+    print("streamed vs layered, %s: max rel %.3g" % (shape, err))
+    assert err <= 5e-6

@@ -5,7 +5,7 @@ R=$(cd $(dirname $0)/.. && pwd)
 P=$R/dcscn-super-resolution_amd
 mkdir -p $R/tools/abl
 if [ "$1" = build ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DSTREAM_DBG -I $R/include -c $P/csrc/feat_stream.hip -o $R/tools/abl/fs_dbg.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DSTREAM_DBG ${EXTRA} -I $R/include -c $P/csrc/feat_stream.hip -o $R/tools/abl/fs_dbg.o || exit 1
   objs=$(ls $P/build/*.o | grep -v feat_stream.o)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $R/tools/abl/fs_dbg.o -o $R/tools/abl/libdcscn_dbg.so || exit 1
 else
