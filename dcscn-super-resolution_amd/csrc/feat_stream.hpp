@@ -101,13 +101,13 @@ __device__ __forceinline__ StreamRow stream_row(const StreamArgs& a, int j0, Str
 
 // bias + PReLU as v + (alpha - 1) * min(v, 0): 4 v_min + 2 v_pk_fma instead of 4 compares, 4 selects and 2 multiplies
 // (`am1` = alpha - 1, precomputed on the host; differs from alpha * v by one rounding of a product that is then added to v)
-__device__ __forceinline__ f32x4 stream_prelu(f32x4 v, f32x4 b, f32x4 am1) {
-    v += b;
-    f32x4 n;
-    n.x = fminf(v.x, 0.0f);
-    n.y = fminf(v.y, 0.0f);
-    n.z = fminf(v.z, 0.0f);
-    n.w = fminf(v.w, 0.0f);
+__device__ __forceinline__ float stream_min0(float v) {
+    // (a hand-written `v_min_f32 n, 0, v` would save the canonicalising v_max fminf() costs -- but the compiler does not see an
+    // asm statement's MFMA -> VALU read hazard, and the v_min read stale accumulators: measured, 3e-4 relative error)
+    return fminf(v, 0.0f);
+}
+__device__ __forceinline__ f32x4 stream_prelu(f32x4 v, f32x4 am1) {
+    const f32x4 n = {stream_min0(v.x), stream_min0(v.y), stream_min0(v.z), stream_min0(v.w)};
     return v + am1 * n;
 }
 
@@ -179,7 +179,7 @@ __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned 
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     if (n * 4 + q < a.first_out.quads) {
-                        const f32x4 r = stream_prelu(pw[n] * d[m], bs[n], al[n]);
+                        const f32x4 r = stream_prelu(pw[n] * d[m] + bs[n], al[n]);
                         stream_st(lds0 + a.first_out.off + ((slot * kStreamRowPx + 3 * j + m + 1) * a.first_out.units + n * 4 + q) * 16u,
                                   ok[m] ? r : kStreamZero);
                     }
@@ -208,8 +208,11 @@ template <int QL> struct StreamChunk {
 // (row dy, the lane's first window pixel, quad 0); the lane's three pixels are window positions 0..2, 1..3, 2..4.
 // acc[m][n] += sum over chunks / k-steps of pointwise[n] x depthwise(pixel m).  QUADS = channel quads of the input ring
 // (compile time: every LDS offset below is an immediate).
+// `init[n]` (the bias) is the C operand of each accumulator's FIRST MFMA: no zero fill, no bias add afterwards -- on this
+// chip every VALU instruction costs matrix-pipe time too (tools/mfma_valu_overlap.hip: they do not overlap).
 template <int QUADS, int NT, int MT = kStreamMT>
-__device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], unsigned lds0, const unsigned (&rowb)[3], int dww, int wpo, int q, int lane) {
+__device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], const f32x4 (&init)[NT], unsigned lds0, const unsigned (&rowb)[3], int dww, int wpo,
+                                             int q, int lane) {
     constexpr int CH = (QUADS + 3) / 4;
     constexpr unsigned PX = (unsigned)(QUADS | 1) * 16u;
     static_for<0, CH>([&](auto ch_) DCSCN_INL {
@@ -221,8 +224,6 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], unsigned lds0
 #pragma unroll
         for (int n = 0; n < NT; ++n) wp[n] = stream_ld(lds0 + wpo + (unsigned)((ch * NT + n) * 64 + lane) * 16u);
         f32x4 d[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) d[m] = kStreamZero;
         const unsigned dwb = lds0 + dww + qoff;
         // rows are double buffered: the reads of row dy + 1 are in flight while row dy is multiplied (the compiler
         // barriers keep it from hoisting all three rows -- 96 VGPRs -- or none)
@@ -235,13 +236,15 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], unsigned lds0
 #pragma unroll
             for (int k = 0; k < MT + 2; ++k) xv[b][k] = STREAM_ABL == 3 ? f32x4{(float)k, (float)lane, 1.0f, 2.0f} : stream_ld(xb + (unsigned)k * PX);
         };
-        auto mult = [&](auto b_) DCSCN_INL {
+        auto mult = [&](auto b_, auto first_) DCSCN_INL {
             constexpr int b = decltype(b_)::value;
+            constexpr bool first = decltype(first_)::value;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    if (STREAM_ABL == 2) { if (dx == 1) d[m] += xv[b][m + dx] + dw[b][dx]; }
+                    if (first && dx == 0) d[m] = dw[b][dx] * xv[b][m + dx];
+                    else if (STREAM_ABL == 2) { if (dx == 1) d[m] += xv[b][m + dx] + dw[b][dx]; }
                     else d[m] += dw[b][dx] * xv[b][m + dx];
                 }
             asm volatile("" ::: "memory");
@@ -251,10 +254,16 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], unsigned lds0
         using I2 = std::integral_constant<int, 2>;
         fetch(I0{}, I0{});
         fetch(I1{}, I1{});
-        mult(I0{});
+        mult(I0{}, std::true_type{});
         fetch(I2{}, I0{});
-        mult(I1{});
-        mult(I0{});
+        mult(I1{}, std::false_type{});
+        mult(I0{}, std::false_type{});
+        if (QL < 3) {
+            // keep the packed depthwise: without this the compiler sinks pick()'s lane-dependent selects into the 9 x (MT + 2)
+            // window values and runs the taps unpacked
+#pragma unroll
+            for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(d[m]));
+        }
         // (lanes of a missing quad hold the depthwise of a real one: finite, times zero filter rows)
 #pragma unroll
         for (int s = 0; s < K::STEPS; ++s)
@@ -263,8 +272,8 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], unsigned lds0
                 const float bv = K::pick(d[m], s, q);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    if (STREAM_ABL == 1) { if (s == 0) acc[m][n] += d[m] * wp[n]; }
-                    else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[n][s], bv, acc[m][n], 0, 0, 0);
+                    if (STREAM_ABL == 1) { if (s == 0) acc[m][n] = (ch == 0 ? init[n] : acc[m][n]) + d[m] * wp[n]; }
+                    else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[n][s], bv, ch == 0 && s == 0 ? init[n] : acc[m][n], 0, 0, 0);
                 }
             }
     });
@@ -282,23 +291,23 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
         const int g = t - c.lag;
         const bool live = g >= 0 && g < rows;
         f32x4 acc[kStreamMT][NT];
-#pragma unroll
-        for (int m = 0; m < kStreamMT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[m][n] = kStreamZero;
+        bool zero_row = true;               // separator / outside the image: the ring gets zeros
         if (live && STREAM_ABL != 5 && STREAM_ABL != 8) {
             const StreamRow ri = stream_row(a, j0, cur, g);
+            zero_row = ri.zero;
             if (!ri.zero) {
                 unsigned rowb[3];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + c.in.off + (unsigned)((g + 2 * c.in.slots - 1 + dy) % c.in.slots) * in_row + (unsigned)(3 * j) * in_px;   // rows g-1, g, g+1
-                stream_dw_pw<QUADS, NT>(acc, lds0, rowb, c.dww, c.wp, q, lane);
+                f32x4 bs[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bs[n] = stream_ld(lds0 + c.ba + (unsigned)(n * 4 + q) * 16u);
+                stream_dw_pw<QUADS, NT>(acc, bs, lds0, rowb, c.dww, c.wp, q, lane);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    const f32x4 bs = stream_ld(lds0 + c.ba + (unsigned)(n * 4 + q) * 16u);
                     const f32x4 al = stream_ld(lds0 + c.ba + 128u + (unsigned)(n * 4 + q) * 16u);
 #pragma unroll
-                    for (int m = 0; m < kStreamMT; ++m) acc[m][n] = stream_prelu(acc[m][n], bs, al);
+                    for (int m = 0; m < kStreamMT; ++m) acc[m][n] = stream_prelu(acc[m][n], al);
                 }
                 if (ri.sx < 0 || ri.sx + kStreamPX > a.W) {          // the strip sticks out of the image: SAME padding is zero
 #pragma unroll
@@ -326,13 +335,12 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
         stream_barrier();
         STREAM_STAMP(a, t, 2);
         if (live && !c.to_global) {
-            const unsigned slot = (unsigned)(g % 3);
+            const unsigned wb = lds0 + c.out.off + (((unsigned)(g % 3) * kStreamRowPx + 3 * j + 1) * c.out.units + q) * 16u;
 #pragma unroll
             for (int m = 0; m < kStreamMT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    if (n * 4 + q < c.out.quads)
-                        stream_st(lds0 + c.out.off + ((slot * kStreamRowPx + 3 * j + m + 1) * c.out.units + n * 4 + q) * 16u, acc[m][n]);
+                    if (n * 4 + q < c.out.quads) stream_st(wb + (unsigned)(m * c.out.units + n * 4) * 16u, zero_row ? kStreamZero : acc[m][n]);
         }
         STREAM_STAMP(a, t, 3);
         stream_barrier();
@@ -418,7 +426,7 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
                         for (int m = 0; m < kStreamMT; ++m) {
                             const int cx = ri.sx + 3 * j + m;
                             const bool ok = !ri.zero && cx >= 0 && cx < a.W;
-                            const f32x4 r = stream_prelu(acc[p][m][n], bs, al);
+                            const f32x4 r = stream_prelu(acc[p][m][n] + bs, al);
                             const f32x4 v = ok ? r : kStreamZero;
                             acc[p][m][n] = kStreamZero;
                             if (n == 0 && q < a.nb_quads)

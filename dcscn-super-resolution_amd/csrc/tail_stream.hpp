@@ -88,22 +88,19 @@ __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArg
         const int g = t - 2;
         const bool live = g >= 0 && g < rows;
         f32x4 acc[1][8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) acc[0][n] = kStreamZero;
+        bool keep = false;                  // false: zero row or a column outside the image -> zeros
         if (live && STREAM_ABL != 11 && STREAM_ABL != 13 && STREAM_ABL != 14) {
             const StreamRow ri = stream_row(geo, j0, cur, g);
             if (!ri.zero) {
                 unsigned rowb[3];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + a.in.off + (unsigned)((g + 2 + dy) % 3) * in_row + (unsigned)px * in_px;
-                stream_dw_pw<QI, 8, 1>(acc, lds0, rowb, a.a_dww, a.a_wp, q, lane);
-                const int cx = ri.sx + px;
-                const bool ok = cx >= 0 && cx < a.W;
+                f32x4 bs[8];
 #pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    const f32x4 bs = stream_ld(lds0 + a.a_bias + (unsigned)(n * 4 + q) * 16u);
-                    acc[0][n] = ok ? acc[0][n] + bs : kStreamZero;
-                }
+                for (int n = 0; n < 8; ++n) bs[n] = stream_ld(lds0 + a.a_bias + (unsigned)(n * 4 + q) * 16u);
+                stream_dw_pw<QI, 8, 1>(acc, bs, lds0, rowb, a.a_dww, a.a_wp, q, lane);
+                const int cx = ri.sx + px;
+                keep = cx >= 0 && cx < a.W;
             }
         }
         stream_barrier();
@@ -114,7 +111,7 @@ __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArg
                 const int ph = tiles == 2 ? n >> 1 : n, quad = (tiles == 2 ? (n & 1) * 4 : 0) + q;
                 const unsigned slot = (unsigned)((2 * g + (ph >> 1)) % kTailUSlots);
                 if (quad < a.u.quads && ph < 4)
-                    stream_st(lds0 + a.u.off + slot * u_row + (unsigned)(2 * px + (ph & 1) + 1) * u_px + (unsigned)quad * 16u, acc[0][n]);
+                    stream_st(lds0 + a.u.off + slot * u_row + (unsigned)(2 * px + (ph & 1) + 1) * u_px + (unsigned)quad * 16u, keep ? acc[0][n] : kStreamZero);
             }
         }
         stream_barrier();
@@ -131,8 +128,7 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
         const int g = t - 4;
         const bool live = g >= 0 && g < rows;
         f32x4 acc[kStreamMT][1];
-#pragma unroll
-        for (int m = 0; m < kStreamMT; ++m) acc[m][0] = kStreamZero;
+        bool okm[kStreamMT] = {false, false, false};
         if (live && STREAM_ABL != 12 && STREAM_ABL != 13 && STREAM_ABL != 14) {
             const StreamRow ri = stream_row(geo, j0, cur, g);
             if (!ri.zero) {
@@ -141,14 +137,13 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
                     rowb[dy] = lds0 + a.u.off + (unsigned)((ur - 1 + dy + kTailUSlots) % kTailUSlots) * u_row + (unsigned)(kStreamPX * half + 3 * j) * u_px;
-                stream_dw_pw<QU, 1>(acc, lds0, rowb, a.b_dww, a.b_wp, q, lane);
-            }
-            const f32x4 bs = stream_ld(lds0 + a.b_bias);
+                const f32x4 bs[1] = {stream_ld(lds0 + a.b_bias)};
+                stream_dw_pw<QU, 1>(acc, bs, lds0, rowb, a.b_dww, a.b_wp, q, lane);
 #pragma unroll
-            for (int m = 0; m < kStreamMT; ++m) {
-                const int cx2 = 2 * ri.sx + kStreamPX * half + 3 * j + m;
-                const bool ok = !ri.zero && cx2 >= 0 && cx2 < 2 * a.W;
-                acc[m][0] = ok ? acc[m][0] + bs : kStreamZero;
+                for (int m = 0; m < kStreamMT; ++m) {
+                    const int cx2 = 2 * ri.sx + kStreamPX * half + 3 * j + m;
+                    okm[m] = cx2 >= 0 && cx2 < 2 * a.W;
+                }
             }
         }
         stream_barrier();
@@ -162,7 +157,7 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     const unsigned slot = (unsigned)((4 * g + 2 * r2 + dy) % kTailVSlots);
-                    const f32x2 v = dy == 0 ? f32x2{acc[m][0].x, acc[m][0].y} : f32x2{acc[m][0].z, acc[m][0].w};
+                    const f32x2 v = !okm[m] ? f32x2{0.0f, 0.0f} : dy == 0 ? f32x2{acc[m][0].x, acc[m][0].y} : f32x2{acc[m][0].z, acc[m][0].w};
                     *(lds_f2)(uintptr_t)(lds0 + a.v_off + (slot * kTailVRow + px4 + 2) * 4u) = v;
                 }
             }
