@@ -177,6 +177,7 @@ struct dcscn_ctx {
     std::vector<std::pair<int, int>> concat_slices;
     uint64_t carve_gen = 0, tables_gen = 0;  // arena carve generation / generation the multi-source tables were filled for
     bool nin = true;                         // wide 1x1 convs on the LDS-DMA staged GEMM (conv_nin); option "nin_gemm" 0 = conv_igemm
+    bool fold_force = false;                 // "fold_linear_tail" 2: fold even where the composite does more work than the layers
     bool fold_tail = true;                   // graph rewrite of the linear tail, see fold_linear_tail(); option "fold_linear_tail" 0 = layer by layer
     bool spatial_tiling = true;              // images larger than one pass are cut into haloed windows (run_tiled)
     std::vector<hipEvent_t> ev;              // event pool: 2 per launch
@@ -685,6 +686,10 @@ bool fold_linear_tail(dcscn_ctx* h) {
     const bool r_ok = (r.kind == OP_COUT1 && r.dw_w < 0) || (r.kind == OP_CONV && r.cout == 1 && r.dwk == 0);
     if (!r_ok || !r.residual || r.segs.size() != 1 || r.segs[0].b >= 0 || r.act != ACT_NONE || r.ks != 3) return false;
     if (r.in_buf != u.out_buf[0] || r.cin != u.ps_c || (u.ps * u.ps + 3) / 4 > 4) return false;
+    // worth it only where the composite does less work: 25 taps x (4 s^2 variants padded to 16-channel tiles) per input
+    // channel against the shuffler conv's 9 s^2 C (the c-DCSCN nets shuffle to ONE channel: 400 vs 36 -- measured 0.53 ms
+    // folded against 0.44 ms layer by layer)
+    if (!h->fold_force && 25 * pad16(4 * u.ps * u.ps) >= 9 * u.ps * u.ps * u.ps_c) return false;
     Op f = u;
     f.name = u.name + "+" + r.name + " (folded)";
     f.ks = 5;
@@ -2039,6 +2044,7 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "fold_linear_tail")) {
         if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the fold_linear_tail option must be set before dcscn_finalize");
         h->fold_tail = value != 0;
+        h->fold_force = value == 2;
         return DCSCN_OK;
     }
     if (!strcmp(key, "stream_tail")) {

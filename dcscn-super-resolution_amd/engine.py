@@ -294,15 +294,16 @@ class Engine:
     def load_weights(self, tensors, winograd=None, fold_tail=None):
         """Feed every variable the graph needs from ``{name: ndarray}`` and finalize.
         ``winograd=False`` keeps every 3x3 conv on the direct implicit-GEMM kernel (default: library choice).
-        ``fold_tail=False`` executes the reference's layers one by one; the library default (also settable with the
-        environment variable DCSCN_FOLD_TAIL=0 / 1) runs the linear tail (last pixel-shuffler conv, depth_to_space,
-        last reconstruction conv) as one 5x5 conv -- see "fold_linear_tail" in include/dcscn.h."""
+        ``fold_tail=False`` executes the reference's layers one by one; the library default runs the linear tail (last
+        pixel-shuffler conv, depth_to_space, last reconstruction conv) as one 5x5 conv where that is less work;
+        ``fold_tail=True`` (or the environment variable DCSCN_FOLD_TAIL=1; =0 for False) folds wherever the graph has
+        such a tail -- see "fold_linear_tail" in include/dcscn.h."""
         if winograd is not None:
             self.set_option("winograd", 1 if winograd else 0)
         if fold_tail is None and os.environ.get("DCSCN_FOLD_TAIL") in ("0", "1"):
             fold_tail = os.environ["DCSCN_FOLD_TAIL"] == "1"
         if fold_tail is not None:
-            self.set_option("fold_linear_tail", 1 if fold_tail else 0)
+            self.set_option("fold_linear_tail", 2 if fold_tail else 0)       # an explicit request folds wherever it is possible
         for name, _ in self.tensor_specs():
             if name not in tensors:
                 raise EngineError(3, "variable '%s' is missing from the checkpoint" % name)

@@ -158,7 +158,9 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * low-resolution map with per-phase / per-border kernels composed in float64 from the checkpoint tensors; the same
  * function, f32 results differ from the layer-by-layer graph by re-association only (parity-tested against the float64
  * oracle at the same 1e-4 bar).  0 = the escape hatch: execute the reference's layers one by one.  Ignored where the
- * graph has no such tail: separable convs, transposed-conv upsampler, reconstruct_layers > 1, cnn_size != 3.
+ * graph has no such tail: separable convs, transposed-conv upsampler, reconstruct_layers > 1, cnn_size != 3 -- and,
+ * with the default value 1, where the composite would be MORE work than the layers (pixel shufflers to fewer than 12
+ * channels at x2: the c-DCSCN nets); 2 folds there too.
  * "dense_features" (default 1; before dcscn_finalize only): every feature layer stores into its own dense NHWC buffer and
  * the 1x1 layer(s) that consume tf.concat (DCSCN.py:234) walk the list of buffers, instead of all layers sharing one
  * [n, h, w, sum C_i] tensor -- same bits, full cache lines.  0 = one concat tensor.  Ignored where a consumer of the
