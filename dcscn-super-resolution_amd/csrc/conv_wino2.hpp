@@ -298,6 +298,8 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
         av[n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         if (act == ACT_ALPHA) av[n] = *reinterpret_cast<const f32x4*>(a.alpha + cbase + n * 16);
     });
+    float m1 = -1.0f;
+    asm volatile("" : "+v"(m1));
     auto finish = [&](auto act_c) DCSCN_INL {
         constexpr int ACT_C = decltype(act_c)::value;
         const int act_e = ACT_C >= 0 ? ACT_C : act;
@@ -323,17 +325,20 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
             const size_t dy = (size_t)ps * orow * ostride;
             const bool live = ok_00 && cc < owidth;
             // t[a][nu] = sum_xi A^T[a][xi] m[xi][nu],  A^T = [1 1 1 0; 0 1 -1 -1]
+            // a - b is written as fma(b, -1, a) with a -1 the compiler cannot see through: there is no packed f32 subtract, so
+            // `a - b` on float4 becomes four v_sub_f32, while this is two v_pk_fma_f32 with the same (exact) result -- and on
+            // this chip every VALU instruction of the epilogue is matrix-pipe time taken from the co-resident workgroup
             f32x4 t0[4], t1[4];
             static_for<0, 4>([&](auto nu_) DCSCN_INL {
                 constexpr int nu = decltype(nu_)::value;
                 t0[nu] = acc[0 + nu][n] + acc[4 + nu][n] + acc[8 + nu][n];
-                t1[nu] = acc[4 + nu][n] - acc[8 + nu][n] - acc[12 + nu][n];
+                t1[nu] = acc[12 + nu][n] * m1 + (acc[8 + nu][n] * m1 + acc[4 + nu][n]);
             });
             f32x4 yv[2][2];
             yv[0][0] = t0[0] + t0[1] + t0[2];
-            yv[0][1] = t0[1] - t0[2] - t0[3];
+            yv[0][1] = t0[3] * m1 + (t0[2] * m1 + t0[1]);
             yv[1][0] = t1[0] + t1[1] + t1[2];
-            yv[1][1] = t1[1] - t1[2] - t1[3];
+            yv[1][1] = t1[3] * m1 + (t1[2] * m1 + t1[1]);
             static_for<0, 2>([&](auto pa_) DCSCN_INL {
                 static_for<0, 2>([&](auto pb_) DCSCN_INL {
                     constexpr int pa = decltype(pa_)::value, pb = decltype(pb_)::value;
