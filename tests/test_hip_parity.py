@@ -447,3 +447,44 @@ def test_streamed_separable_net_matches_layer_by_layer(oracle, shape):
     err = np.abs(outs[1] - outs[0]).max() / scale
     print("streamed vs layered, %s: max rel %.3g" % (shape, err))
     assert err <= 5e-6
+
+
+# (layers, filters, min_filters, gamma, nin_filters, nin_filters2, scale, activator): between them every instantiated
+# stream_conv_role<input quads 1..8, output tiles 1..2> and every last-chunk width of the A1 || B1 sources
+STREAM_VARIANTS = [
+    (7, 32, 8, 1.2, 24, 8, 2, "prelu"),        # the shipped widths at x2: feat_stream + per-layer tail
+    (7, 32, 8, 1.2, 24, 8, 3, "prelu"),
+    (5, 29, 3, 1.0, 20, 12, 4, "relu"),        # quads 8, 6, 4, 2 -> ...; B2 from 12 channels (3 quads)
+    (6, 24, 1, 1.5, 9, 5, 2, "leaky_relu"),    # down to one channel: a single-quad source and a 1-quad conv input
+    (4, 20, 16, 1.0, 16, 16, 2, "prelu"),      # 5 quads in, 2 output tiles would be <5,2>: not instantiated -> layer by layer
+    (3, 32, 17, 2.0, 8, 4, 4, "prelu"),        # 8 quads -> 2 tiles, then 5 quads -> ...
+    (2, 16, 13, 1.0, 28, 4, 3, "prelu"),
+]
+
+
+@pytest.mark.parametrize("variant", STREAM_VARIANTS)
+def test_feat_stream_variants(oracle, variant):
+    """Separable nets of other depths / widths than the shipped one: the streamed feature extractor must be taken wherever
+    its role instantiations cover the net (and only there), and meet the bare-branch bar against the float64 oracle."""
+    from dcscn_amd import engine
+    layers, filters, min_filters, gamma, na, nb, scale, act = variant
+    cfg = oracle.make_config(layers=layers, filters=filters, min_filters=min_filters, filters_decay_gamma=gamma, nin_filters=na,
+                             nin_filters2=nb, scale=scale, activator=act, depthwise_separable=True, reconstruct_layers=0,
+                             pixel_shuffler_filters=1)
+    weights = oracle.synthetic_weights(cfg, seed=layers * 10 + scale)
+    x, x2 = synthetic_batch(2, 37, 55, scale, seed=5)
+    x2 = np.zeros_like(x2)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with engine.Engine(cfg, device=0) as eng:
+        eng.load_weights(weights)
+        kernels = [o["kernel"] for o in eng.ops()]
+        y = eng.forward(x, x2).astype(np.float64)
+    sched = oracle.filter_schedule(layers, filters, min_filters, gamma)
+    quads = lambda c: (c + 3) // 4
+    pairs = [(quads(sched[i]), (sched[i + 1] + 15) // 16) for i in range(layers - 1)] + [(quads(nb), (nb + 15) // 16)]
+    supported = all((t == 1) if qi <= 5 else (t == 2) if qi <= 7 else True for qi, t in pairs)
+    assert ("feat_stream" in kernels) == supported, (kernels, sched, pairs)
+    scale_ = np.abs(ref).max()
+    err = np.abs(y - ref).max() / scale_
+    print(variant, kernels[:2], "max rel %.3g" % err)
+    assert err <= 5e-6
