@@ -359,23 +359,24 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
             for (int n = 0; n < 2; ++n) acc[p][m][n] = kStreamZero;
     StreamCursor cur[2];       // the wave alternates between an even and an odd row; each advances by 2L rows at a time
 
-    for (int t = 0; t < T; ++t) {
+    // the step loop is unrolled by two so that the row parity (which accumulator set) is a compile-time constant: a run-time
+    // choice costs ~45 register moves per step, and VALU time is matrix time here.  l advances by one every second step.
+    int l = ((0 - w) % L + L) % L;
+    if (l == 0) l = L;
+    auto step = [&](auto p_, int t) DCSCN_INL {
+        constexpr int p = decltype(p_)::value;
         STREAM_STAMP(a, t, 0);
         // (opaque per step: otherwise every lane-derived address of every branch is hoisted out of the loop and spilled)
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));
         const int j = lane & 15, q = lane >> 4;
         // row g = t + 1 - 2l receives layer l's contribution at step t; (g >> 1) mod L == w picks this wave's l
-        const int hl = (t + 1) >> 1;
-        int l = ((hl - w) % L + L) % L;
-        if (l == 0) l = L;
-        const int g = t + 1 - 2 * l;
+        const int g = t + 1 - 2 * l;                   // parity of g = parity of t + 1 = p
         const bool live = g >= 0 && g < rows;
         const bool last = l == L;
         if (live && STREAM_ABL != 6 && STREAM_ABL != 8) {
             const StreamNinSrc& s = a.nin[l - 1];
-            auto body = [&](auto p_) DCSCN_INL {
-                constexpr int p = decltype(p_)::value;
+            {
                 const StreamRow ri = stream_row(a, j0, cur[p], g);
                 if (!ri.zero) {
                     const unsigned rowb = lds0 + s.ring.off + ((unsigned)(g % 3) * kStreamRowPx + 3 * j + 1) * (unsigned)s.ring.units * 16u;
@@ -436,15 +437,20 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
                         }
                     }
                 }
-            };
-            if (g & 1) body(std::integral_constant<int, 1>{});
-            else body(std::integral_constant<int, 0>{});
+            }
         }
         STREAM_STAMP(a, t, 1);
         stream_barrier();
         STREAM_STAMP(a, t, 2);
         STREAM_STAMP(a, t, 3);
         stream_barrier();
+    };
+    for (int t = 0; t < T; t += 2) {
+        step(std::integral_constant<int, 1>{}, t);
+        if (t + 1 < T) {
+            l = l == L ? 1 : l + 1;
+            step(std::integral_constant<int, 0>{}, t + 1);
+        }
     }
 }
 
