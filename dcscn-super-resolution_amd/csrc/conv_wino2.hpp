@@ -195,13 +195,17 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
         asm volatile("" : "+v"(be), "+v"(bo));               // keep them out of the loop-invariant (long-lived) set
     };
     // the 16*NTV MFMAs of one k-step, filter operands read PF frequencies ahead; hook(f) runs after the MFMAs of f
-    auto mfma_step = [&](const float* Bs, const float (&v)[16], auto&& hook) DCSCN_INL {
+    // filter operands are read as single ds_read_b32 with 16-bit immediate offsets (volatile LDS pointer): paired into
+    // ds_read2_b32 -- 8-bit offsets -- every pair needs a v_add for its base, 24 VALU instructions per chunk, and VALU time is
+    // matrix time on this chip
+    typedef const volatile __attribute__((address_space(3))) float* lds_f32_ptr;
+    auto mfma_step = [&](unsigned Bs, const float (&v)[16], auto&& hook) DCSCN_INL {
         float wq[PF + 1][NTV];
         static_for<0, PF>([&](auto p_) DCSCN_INL {
             constexpr int pf = decltype(p_)::value;
             static_for<0, NTV>([&](auto n_) DCSCN_INL {
                 constexpr int n = decltype(n_)::value;
-                wq[pf][n] = Bs[(pf * G::KC) * G::NS + n * 16];
+                wq[pf][n] = *(lds_f32_ptr)(uintptr_t)(Bs + ((pf * G::KC) * G::NS + n * 16) * 4);
             });
         });
         static_for<0, 16>([&](auto f_) DCSCN_INL {
@@ -209,7 +213,7 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
             if constexpr (f + PF < 16) {
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
                     constexpr int n = decltype(n_)::value;
-                    wq[(f + PF) % (PF + 1)][n] = Bs[((f + PF) * G::KC) * G::NS + n * 16];
+                    wq[(f + PF) % (PF + 1)][n] = *(lds_f32_ptr)(uintptr_t)(Bs + (((f + PF) * G::KC) * G::NS + n * 16) * 4);
                 });
             }
             static_for<0, NTV>([&](auto n_) DCSCN_INL {
@@ -252,7 +256,7 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
         const unsigned sb = chunk & 1;
         const bool more_b = chunk + 1 <= last;               // filters of chunk c+1 / input of chunk c+2 exist (wave uniform)
         const bool more_a = chunk + 2 <= last;
-        const float* Bs = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + b_lane + sb * G::B_BYTES);
+        const unsigned Bs = lds0 + (unsigned)b_lane + sb * G::B_BYTES;
         const unsigned An = lds0 + (sb ^ 1) * G::A_BYTES;
         unsigned be = 0, bo = 0;
         float v[16];
@@ -267,7 +271,7 @@ __device__ __forceinline__ void conv_wino2_body(const ConvArgs& a, float* smem, 
             }
         });
         transform(std::integral_constant<int, 1>{}, rr, v);
-        mfma_step(Bs + 4 * G::NS, v, [&](auto f_) DCSCN_INL {
+        mfma_step(Bs + 4 * G::NS * 4, v, [&](auto f_) DCSCN_INL {
             constexpr int f = decltype(f_)::value;
             // raw patch of the next chunk, two elements behind each of the last 8 frequencies
             if constexpr (f == 7) lane_bases(An, be, bo);
