@@ -5,11 +5,12 @@
 // 32-channel Concat2).  Here a workgroup owns a 48-pixel-wide column strip of an image and walks down its rows; every
 // layer keeps only a THREE-ROW ring of its output in LDS, which is all the next 3x3 layer needs:
 //
-//   wave 0            CNN1: depthwise 3x3 on Y (global, prefetched one step ahead) -> pointwise 1 -> C1, VALU only
-//   waves 1 .. L-1    CNN2 .. CNNL: depthwise 3x3 (VALU, from the predecessor's ring) -> pointwise GEMM on the MFMA
-//                     pipe (filters re-read from L1 / L2 every row: 4 KB) -> bias, PReLU -> own ring
-//   wave L            B2: the same, from the B1 ring to global Concat2[0 : nb)
-//   waves L+1 .. 2L   A1 || B1: H_concat never exists.  The 1x1 layers are linear in the concat, so the contribution of
+// (which wave plays which role is a table, StreamArgs::role, filled so that the MFMA counts of the four SIMDs are even)
+//   1 wave            CNN1: depthwise 3x3 on Y (global, prefetched one step ahead) -> pointwise 1 -> C1, VALU only
+//   L-1 waves         CNN2 .. CNNL: depthwise 3x3 (VALU, from the predecessor's ring) -> pointwise GEMM on the MFMA
+//                     pipe (filters in LDS, the bias is the first MFMA's C operand) -> PReLU -> own ring
+//   1 wave            B2: the same, from the B1 ring to global Concat2[0 : nb)
+//   L waves           A1 || B1: H_concat never exists.  The 1x1 layers are linear in the concat, so the contribution of
 //                     feature layer l to row g is accumulated as soon as that row is in layer l's ring; the L rows in
 //                     flight are spread over L waves (row g -> wave (g/2) mod L, two rows per wave in registers), each of
 //                     which therefore does exactly one (layer, row) contribution per step.
@@ -25,9 +26,13 @@
 // ds_read_b128 = channels 4q' .. 4q'+3 (q' = 4 * chunk + q) of a pixel and uses its four floats as the B operand of four
 // k-steps; k-step s of a chunk therefore covers channels {16 chunk + 4q + s}, and the filters are packed to match.
 // Column j of pixel tile m is pixel 3j + m, not 16m + j: a lane's three pixels are neighbours, so the 3x3 depthwise
-// window of all three needs 5 reads per row instead of 9 (LDS bandwidth is the second limiter after the MFMA pipe).
-// Ring rows are [pixel -1 .. 48][units] float4 with an ODD number of units per pixel: the 16 lanes of a ds_read_b128
-// phase hit 16 different 16-byte bank groups.
+// window of all three needs 5 reads per row instead of 9.  Ring rows are [pixel -1 .. 48][units] float4 with an odd number
+// of units per pixel.  (ds_read_b128 lane groups mix two lane quarters, MI355X_MICROARCH.md, so these reads are still 2-way
+// conflicted; a planar [quad][pixel] layout that is conflict free was measured at the same time -- DESIGN.md 3.7.)
+//
+// What bounds it: f32 MFMA does not overlap with VALU instructions of other waves on a SIMD (tools/mfma_valu_overlap.hip),
+// so a row costs 32 cycles per MFMA PLUS ~4.5 per VALU instruction per SIMD; the code below is written to keep the
+// non-FMA instruction count down (immediate LDS offsets, compile-time ring geometry, masks only at image edges).
 #pragma once
 #include "conv_igemm.hpp"
 
