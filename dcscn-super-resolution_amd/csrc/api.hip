@@ -1869,31 +1869,61 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
     a.ldsw_bytes = lds - a.ring_bytes;
     if ((size_t)a.ldsw_bytes != blob.size() * sizeof(float)) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat_stream LDS image size");
     {
-        // wave -> role: wave w runs on SIMD w & 3 and the matrix pipe is per SIMD, so spread the MFMA counts (heaviest first,
-        // always onto the least loaded SIMD that still has a wave left)
+        // wave -> role: wave w runs on SIMD w & 3, and on a SIMD the MFMAs and the VALU instructions of all its waves execute
+        // one after the other (tools/mfma_valu_overlap.hip), so a SIMD's time per row is the SUM of its roles' estimated cycles
+        // (32 per MFMA + 4.5 per other VALU instruction).  Exhaustive search for the assignment with the smallest maximum:
+        // the L A1 || B1 roles are interchangeable, the other L + 1 roles are tried on every SIMD (4^(L+1) <= 65536).
         auto ksteps = [](int quads) { const int ch = (quads + 3) / 4, ql = quads - 4 * (ch - 1); return 4 * (ch - 1) + (ql >= 3 ? 4 : ql); };
-        std::vector<std::pair<int, int>> roles;           // (MFMAs per row, role code)
-        roles.push_back({0, 0});
-        int nin_total = 0;
+        std::vector<int> cost(1 + L), code(1 + L);
+        cost[0] = (int)(4.5 * 180); code[0] = 0;                  // CNN1
+        int nin_mfma = 0;
         for (int i = 0; i < L; ++i) {
-            roles.push_back({3 * ((a.conv[i].out.quads + 3) / 4) * ksteps(a.conv[i].in.quads), 1 + i});
-            nin_total += 6 * ksteps(fr[i].quads);
+            const int chunks = (a.conv[i].in.quads + 3) / 4, tiles = (a.conv[i].out.quads + 3) / 4;
+            cost[1 + i] = 32 * 3 * tiles * ksteps(a.conv[i].in.quads) + (int)(4.5 * (54 * chunks + 36 * tiles + 100));
+            code[1 + i] = 1 + i;
+            nin_mfma += 6 * ksteps(fr[i].quads);
         }
-        for (int i = 0; i < L; ++i) roles.push_back({nin_total / L, 16 + i});
-        std::sort(roles.begin(), roles.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });
+        const int nin_cost = 32 * nin_mfma / L + (int)(4.5 * 85);
         const int waves = 2 * L + 1;
-        int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
-        for (int w = 0; w < 16; ++w) a.role[w] = 0;
-        for (const auto& r : roles) {
-            int best = -1;
-            for (int sd = 0; sd < 4; ++sd) {
-                if (sd + 4 * used[sd] >= waves) continue;
-                if (best < 0 || load[sd] < load[best]) best = sd;
+        int cap[4];
+        for (int sd = 0; sd < 4; ++sd) cap[sd] = (waves - sd + 3) / 4;      // waves sd, sd + 4, ... below `waves`
+        long best_key = -1;
+        std::vector<int> best_sd(1 + L, 0);
+        int best_nin[4] = {0, 0, 0, 0};
+        const int combos = 1 << (2 * (L + 1));
+        for (int m = 0; m < combos; ++m) {
+            int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+            for (int r = 0; r <= L; ++r) { const int sd = (m >> (2 * r)) & 3; load[sd] += cost[r]; used[sd] += 1; }
+            if (used[0] > cap[0] || used[1] > cap[1] || used[2] > cap[2] || used[3] > cap[3]) continue;
+            // the L interchangeable roles: always onto the least loaded SIMD with a free wave
+            int nin[4] = {0, 0, 0, 0};
+            bool ok = true;
+            for (int k = 0; k < L && ok; ++k) {
+                int pick = -1;
+                for (int sd = 0; sd < 4; ++sd)
+                    if (used[sd] + nin[sd] < cap[sd] && (pick < 0 || load[sd] < load[pick])) pick = sd;
+                if (pick < 0) { ok = false; break; }
+                nin[pick] += 1;
+                load[pick] += nin_cost;
             }
-            a.role[best + 4 * used[best]] = (int8_t)r.second;
-            used[best] += 1;
-            load[best] += r.first;
+            if (!ok) continue;
+            const long mx = std::max(std::max(load[0], load[1]), std::max(load[2], load[3]));
+            long sq = 0;
+            for (int sd = 0; sd < 4; ++sd) sq += (long)(load[sd] / 16) * (load[sd] / 16);
+            const long key = mx * 1000000 + sq / 16;
+            if (best_key < 0 || key < best_key) {
+                best_key = key;
+                for (int r = 0; r <= L; ++r) best_sd[r] = (m >> (2 * r)) & 3;
+                for (int sd = 0; sd < 4; ++sd) best_nin[sd] = nin[sd];
+            }
         }
+        if (best_key < 0) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat_stream role placement");
+        int used[4] = {0, 0, 0, 0};
+        for (int w = 0; w < 16; ++w) a.role[w] = 0;
+        for (int r = 0; r <= L; ++r) { const int sd = best_sd[r]; a.role[sd + 4 * used[sd]] = (int8_t)code[r]; used[sd] += 1; }
+        int slot = 0;
+        for (int sd = 0; sd < 4; ++sd)
+            for (int k = 0; k < best_nin[sd]; ++k) { a.role[sd + 4 * used[sd]] = (int8_t)(16 + slot); used[sd] += 1; slot += 1; }
     }
     if (lds > 160 * 1024) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat_stream needs %d bytes of LDS", lds);
 
