@@ -245,10 +245,15 @@ __global__ __launch_bounds__(640) void tail_stream(const TailArgs a) {
     const int j1 = min(a.n_jobs, j0 + a.jobs_per_wg);
     const int rows = (j1 - j0) * (a.rows_c + 1);
     const int T = rows + 6;
-    if (wave == 0) tail_load_role(a, geo, lds0, j0, rows, T, lane);
-    else if (wave <= 3) tail_up1_role<8>(a, geo, wave - 1, lds0, j0, rows, T, lane);      // instantiated for 32 -> 4 x 32 -> 4 channels (api.hip: fuse_tail_stream)
-    else if (wave <= 7) tail_up2_role<8>(a, geo, (wave - 4) >> 1, (wave - 4) & 1, lds0, j0, rows, T, lane);
-    else tail_rec_role(a, geo, wave - 8, lds0, j0, rows, T, lane);
+    // wave -> role so that the four SIMDs (wave w runs on SIMD w & 3; MFMA and VALU time of a SIMD's waves add up) carry about
+    // the same estimated cycles per row: SIMD0 = two Up-PS2 waves + the loader, SIMD1 = one Up-PS wave + both R-CNN1 waves,
+    // SIMD2 and SIMD3 = one Up-PS + one Up-PS2 wave each.  0 loader, 1..3 Up-PS, 4..7 Up-PS2, 8..9 R-CNN1.
+    constexpr int kRole[10] = {4, 1, 2, 3, 5, 8, 6, 7, 0, 9};
+    const int role = kRole[wave];
+    if (role == 0) tail_load_role(a, geo, lds0, j0, rows, T, lane);
+    else if (role <= 3) tail_up1_role<8>(a, geo, role - 1, lds0, j0, rows, T, lane);      // instantiated for 32 -> 4 x 32 -> 4 channels (api.hip: fuse_tail_stream)
+    else if (role <= 7) tail_up2_role<8>(a, geo, (role - 4) >> 1, (role - 4) & 1, lds0, j0, rows, T, lane);
+    else tail_rec_role(a, geo, role - 8, lds0, j0, rows, T, lane);
 }
 
 }  // namespace dcscn
