@@ -22,7 +22,7 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-source extra flags (see the comment at the top of conv_wino2.hip)
 EXTRA_FLAGS = {"conv_wino2.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"],
-               "conv_nin.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "color.hip": ["-ffp-contract=off"], "feat_stream.hip": ["-Rpass-analysis=kernel-resource-usage"]}
+               "conv_nin.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "color.hip": ["-ffp-contract=off"], "feat_stream.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"]}
 # kernels that sit at the VGPR limit by design (192 accumulators + operands): a register spill inside their K loop also
 # breaks the hand-counted vmcnt accounting of the LDS-DMA pipeline, so a build that spills is rejected, not shipped
 NO_SCRATCH = ("conv_wino2.hip", "conv_nin.hip", "feat_stream.hip")
