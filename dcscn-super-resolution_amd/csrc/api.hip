@@ -639,7 +639,7 @@ int op_tiles16(const Op& op) {
 }
 
 // Winograd F(2x2,3x3) (conv_wino2) for 3x3 convs with enough input channels to amortise the transforms (measured on
-// MI355X: 1.25-1.35x over conv_igemm from 57 input channels up; the tiny layers of the c-DCSCN models stay on the direct
+// MI355X: 1.25-1.35x over conv_igemm from 57 input channels up, still 1.3x at 22-26; the last, single-tile layers of the c-DCSCN models stay on the direct
 // kernel).  A layer's 16-channel tiles are spread evenly over ceil(tiles / 3) channel groups (10 tiles = 3+3+2+2): a
 // group's cost is only partly its MFMA count (the input tile and its transform are per group), so a 1-tile group costs
 // ~70 % of a 3-tile one.  (op.vec4: the Winograd epilogue only has the 16-byte store form.)
