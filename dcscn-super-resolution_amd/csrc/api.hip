@@ -675,7 +675,8 @@ bool wino_eligible(const dcscn_ctx* h, const Op& op) {
 // 25 * Cin * 4 s^2 MACs per LR pixel replace 9 * Cin * s^2 C + 9 s^2 C (C = 96, s = 2: 38 k instead of 335 k),
 // and the s^2 C-channel HR map is never written.  The result equals the layer-by-layer graph in exact
 // arithmetic; in f32 it differs by re-association (composite weights are formed in float64 and rounded
-// once).  Opt-in (option "fold_linear_tail"), because it no longer executes the reference's layers one by one.
+// once).  On by default where the composite is less work than the layers (option "fold_linear_tail": 0 = the reference's
+// layers one by one, 2 = fold even where it is more work).
 bool fold_linear_tail(dcscn_ctx* h) {
     const dcscn_config& c = h->cfg;
     if (!c.pixel_shuffler || c.depthwise_separable || c.cnn_size != 3 || c.reconstruct_layers > 1) return false;
