@@ -159,35 +159,36 @@ __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned 
             for (int k = 0; k < 5; ++k) xw[s][k] = xw[s + 1][k];
         load_row(g + 2, xw[3]);
         const bool live = g < rows;
-        float d[kStreamMT];
-        bool ok[kStreamMT];
+        // (everything but the stores happens in the compute phase: VALU work in the write phase delays the SIMD's other waves)
+        f32x4 v[kStreamMT][2];
         if (live) {
             const StreamRow ri = stream_row(a, j0, cc, g);
 #pragma unroll
             for (int m = 0; m < kStreamMT; ++m) {
-                d[m] = 0.0f;
+                float d = 0.0f;
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) d[m] = fmaf(w9[dy * 3 + dx], xw[dy][m + dx], d[m]);
+                    for (int dx = 0; dx < 3; ++dx) d = fmaf(w9[dy * 3 + dx], xw[dy][m + dx], d);
                 const int cx = ri.sx + 3 * j + m;
-                ok[m] = !ri.zero && cx >= 0 && cx < a.W;
+                const bool ok = !ri.zero && cx >= 0 && cx < a.W;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const f32x4 r = stream_prelu(pw[n] * d + bs[n], al[n]);
+                    v[m][n] = ok ? r : kStreamZero;
+                }
             }
         }
         STREAM_STAMP(a, t, 1);
         stream_barrier();
         STREAM_STAMP(a, t, 2);
         if (live) {
-            const unsigned slot = (unsigned)(g % 3);
+            const unsigned wb = lds0 + a.first_out.off + (((unsigned)(g % 3) * kStreamRowPx + 3 * j + 1) * a.first_out.units + q) * 16u;
 #pragma unroll
             for (int m = 0; m < kStreamMT; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    if (n * 4 + q < a.first_out.quads) {
-                        const f32x4 r = stream_prelu(pw[n] * d[m] + bs[n], al[n]);
-                        stream_st(lds0 + a.first_out.off + ((slot * kStreamRowPx + 3 * j + m + 1) * a.first_out.units + n * 4 + q) * 16u,
-                                  ok[m] ? r : kStreamZero);
-                    }
+                    if (n * 4 + q < a.first_out.quads) stream_st(wb + (unsigned)(m * a.first_out.units + n * 4) * 16u, v[m][n]);
         }
         STREAM_STAMP(a, t, 3);
         stream_barrier();
@@ -345,7 +346,10 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
             for (int m = 0; m < kStreamMT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    if (n * 4 + q < c.out.quads) stream_st(wb + (unsigned)(m * c.out.units + n * 4) * 16u, zero_row ? kStreamZero : acc[m][n]);
+                    if (n * 4 + q < c.out.quads) {
+                        if (zero_row) stream_st(wb + (unsigned)(m * c.out.units + n * 4) * 16u, kStreamZero);       // wave uniform
+                        else stream_st(wb + (unsigned)(m * c.out.units + n * 4) * 16u, acc[m][n]);
+                    }
         }
         STREAM_STAMP(a, t, 3);
         stream_barrier();
