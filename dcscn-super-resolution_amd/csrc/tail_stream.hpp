@@ -89,6 +89,7 @@ __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArg
         const bool live = g >= 0 && g < rows;
         f32x4 acc[1][8];
         bool keep = false;                  // false: zero row or a column outside the image -> zeros
+        bool inside = false;                // wave uniform: the whole strip lies inside the image (no per-lane select needed)
         if (live && STREAM_ABL != 11 && STREAM_ABL != 13 && STREAM_ABL != 14) {
             const StreamRow ri = stream_row(geo, j0, cur, g);
             if (!ri.zero) {
@@ -101,6 +102,7 @@ __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArg
                 stream_dw_pw<QI, 8, 1>(acc, bs, lds0, rowb, a.a_dww, a.a_wp, q, lane);
                 const int cx = ri.sx + px;
                 keep = cx >= 0 && cx < a.W;
+                inside = ri.sx >= 0 && ri.sx + kStreamPX <= a.W;
             }
         }
         stream_barrier();
@@ -110,8 +112,11 @@ __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArg
             for (int n = 0; n < 8; ++n) {
                 const int ph = tiles == 2 ? n >> 1 : n, quad = (tiles == 2 ? (n & 1) * 4 : 0) + q;
                 const unsigned slot = (unsigned)((2 * g + (ph >> 1)) % kTailUSlots);
-                if (quad < a.u.quads && ph < 4)
-                    stream_st(lds0 + a.u.off + slot * u_row + (unsigned)(2 * px + (ph & 1) + 1) * u_px + (unsigned)quad * 16u, keep ? acc[0][n] : kStreamZero);
+                if (quad < a.u.quads && ph < 4) {
+                    const unsigned dst = lds0 + a.u.off + slot * u_row + (unsigned)(2 * px + (ph & 1) + 1) * u_px + (unsigned)quad * 16u;
+                    if (inside) stream_st(dst, acc[0][n]);
+                    else stream_st(dst, keep ? acc[0][n] : kStreamZero);
+                }
             }
         }
         stream_barrier();
@@ -129,6 +134,7 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
         const bool live = g >= 0 && g < rows;
         f32x4 acc[kStreamMT][1];
         bool okm[kStreamMT] = {false, false, false};
+        bool inside = false;                // wave uniform: the strip lies inside the image
         if (live && STREAM_ABL != 12 && STREAM_ABL != 13 && STREAM_ABL != 14) {
             const StreamRow ri = stream_row(geo, j0, cur, g);
             if (!ri.zero) {
@@ -144,6 +150,7 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
                     const int cx2 = 2 * ri.sx + kStreamPX * half + 3 * j + m;
                     okm[m] = cx2 >= 0 && cx2 < 2 * a.W;
                 }
+                inside = ri.sx >= 0 && ri.sx + kStreamPX <= a.W;
             }
         }
         stream_barrier();
@@ -157,7 +164,8 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
                     const unsigned slot = (unsigned)((4 * g + 2 * r2 + dy) % kTailVSlots);
-                    const f32x2 v = !okm[m] ? f32x2{0.0f, 0.0f} : dy == 0 ? f32x2{acc[m][0].x, acc[m][0].y} : f32x2{acc[m][0].z, acc[m][0].w};
+                    f32x2 v = dy == 0 ? f32x2{acc[m][0].x, acc[m][0].y} : f32x2{acc[m][0].z, acc[m][0].w};
+                    if (!inside && !okm[m]) v = f32x2{0.0f, 0.0f};
                     *(lds_f2)(uintptr_t)(lds0 + a.v_off + (slot * kTailVRow + px4 + 2) * 4u) = v;
                 }
             }
