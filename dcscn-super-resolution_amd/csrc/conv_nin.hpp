@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, WPS) void conv_nin(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const long long pix0 = (long long)blockIdx.x * NinGeom<NT>::PIX;
     const int ntile = blockIdx.y;
+    if (a.redo_check && a.redo[blockIdx.x] == 0) return;       // fallback behind conv_nin_h: only the flagged pixel blocks
     if (ntile < a.n_full) conv_nin_body<NT, NT, MULTI>(a, smem, pix0, ntile);          // block uniform
     else if constexpr (NT >= 2) conv_nin_body<NT, NT - 1, MULTI>(a, smem, pix0, ntile);
 }

@@ -1,0 +1,52 @@
+// conv_nin_h variants (conv_nin_h.hpp), one translation unit to parallelise the build.
+#include "conv_nin_h.hpp"
+
+namespace dcscn {
+
+constexpr int kNinHMaxTable = 16 * 1024;         // LDS bytes for the multi-source quad table (conv_nin.hip: kNinMaxTable)
+
+template <int NT>
+static hipError_t nin_h_set_attr() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin_h<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, NinHGeom<NT>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin_h<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               NinHGeom<NT>::LDS_BYTES + kNinHMaxTable);
+}
+
+hipError_t nin_h_init_kernels() {
+    hipError_t e = nin_h_set_attr<1>();
+    if (e == hipSuccess) e = nin_h_set_attr<2>();
+    if (e == hipSuccess) e = nin_h_set_attr<3>();
+    if (e == hipSuccess) e = nin_h_set_attr<4>();
+    if (e == hipSuccess) e = nin_h_set_attr<5>();
+    return e != hipSuccess ? e : nin_h_set_attr<6>();
+}
+
+template <int NT>
+static hipError_t nin_h_launch_one(const ConvArgs& a, int n_groups, hipStream_t stream) {
+    const long long npix = (long long)a.N * a.H * a.W;
+    const dim3 grid((unsigned)((npix + NinHGeom<NT>::PIX - 1) / NinHGeom<NT>::PIX), (unsigned)n_groups);
+    if (a.srctab) {
+        const size_t table = (size_t)a.n_chunks * 64;
+        if (table > (size_t)kNinHMaxTable) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((conv_nin_h<NT, true>), grid, dim3(256), NinHGeom<NT>::LDS_BYTES + table, stream, a);
+    } else {
+        hipLaunchKernelGGL((conv_nin_h<NT, false>), grid, dim3(256), NinHGeom<NT>::LDS_BYTES, stream, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t nin_h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream) {
+    if (a.n_full < 1 || a.n_full > n_groups || (nt == 1 && a.n_full != n_groups) || !a.wpack16) return hipErrorInvalidValue;
+    switch (nt) {
+        case 1: return nin_h_launch_one<1>(a, n_groups, stream);
+        case 2: return nin_h_launch_one<2>(a, n_groups, stream);
+        case 3: return nin_h_launch_one<3>(a, n_groups, stream);
+        case 4: return nin_h_launch_one<4>(a, n_groups, stream);
+        case 5: return nin_h_launch_one<5>(a, n_groups, stream);
+        case 6: return nin_h_launch_one<6>(a, n_groups, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dcscn

@@ -385,6 +385,7 @@ __global__ __launch_bounds__(256, WPS) void conv_wino2(const ConvArgs a) {
     const int ntile = phase * S + (r >> 3);
     const int tile_id = q * 8 + (r & 7);
     if (tile_id >= a.N * a.tiles_y * a.tiles_x) return;
+    if (a.redo_check && a.redo[tile_id] == 0) return;          // fallback behind conv3_h: only the flagged pixel tiles
     if (ntile < a.n_full) conv_wino2_body<NT, NT, PF, ABL>(a, smem, tile_id, ntile);                 // block uniform
     else if constexpr (NT >= 2) conv_wino2_body<NT, NT - 1, PF, ABL>(a, smem, tile_id, ntile);
 }

@@ -58,6 +58,12 @@ struct ConvArgs {
     // position and stores one value per HR pixel into out0 (stride 1), plus `res`.
     int32_t fold;
     const void* srctab;       // conv_nin, multi-source input: device array of NinSrcQuad, 4 * n_chunks entries (nullptr: `in` is one tensor)
+    // split16 kernels (split16.hpp: f32-accurate contraction on the f16 matrix pipe)
+    const void* wpack16;      // filters as f16 (hi, lo) fragments (split16_pack.hpp), scaled by 2^e
+    float inv_scale;          // 2^-e
+    int32_t* redo;            // one flag per unit (conv_nin: block of 256 pixels; 3x3: 16x16 pixel tile): a split16 kernel sets
+                              // redo[unit] = 1 when an output of the unit is not finite (an activation beyond the f16 range)
+    int32_t redo_check;       // f32 kernels: 1 = run only the units whose flag is set (the launch behind a split16 kernel)
 };
 
 struct ConvShape {            // kernel variant picked by the plan
@@ -94,6 +100,9 @@ constexpr int kNinKC = 16;
 constexpr int kNinMaxNT = 6;
 hipError_t nin_init_kernels();
 hipError_t nin_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
+// the same on the f16 matrix pipe (conv_nin_h.hpp); args.wpack16 = pack_nin16 image, args.inv_scale, args.redo
+hipError_t nin_h_init_kernels();
+hipError_t nin_h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
 
 // ---- row-streamed feature extractor of the separable narrow nets (feat_stream.hpp) ----
 constexpr int kStreamPX = 48;                  // computed columns per strip: three 16-pixel MFMA tiles
