@@ -1,0 +1,44 @@
+// conv3_h variants (conv3_h.hpp), one translation unit to parallelise the build.
+#include "conv3_h.hpp"
+
+namespace dcscn {
+
+template <int NT>
+static hipError_t c3h_set_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_h<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, C3HGeom<NT>::LDS_BYTES);
+}
+
+hipError_t c3h_init_kernels() {
+    hipError_t e = c3h_set_attr<1>();
+    if (e == hipSuccess) e = c3h_set_attr<2>();
+    if (e == hipSuccess) e = c3h_set_attr<3>();
+    return e != hipSuccess ? e : c3h_set_attr<4>();
+}
+
+// 1-D grid as wino_launch's: groups of one pixel tile congruent mod 8 and close together (conv3_h.hpp)
+template <int NT>
+static hipError_t c3h_launch_one(ConvArgs a, int n_groups, hipStream_t stream) {
+    a.n_groups = n_groups;
+    a.group_span = n_groups < 3 ? n_groups : 3;
+    const long long tiles = (long long)a.N * a.tiles_y * a.tiles_x;
+    const int phases = (n_groups + a.group_span - 1) / a.group_span;
+    const long long ids = ((tiles + 7) / 8) * 8 * a.group_span * phases;
+    if (ids > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv3_h<NT>), dim3((unsigned)ids), dim3(256), C3HGeom<NT>::LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t c3h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream) {
+    if (a.n_full < 1 || a.n_full > n_groups || (nt == 1 && a.n_full != n_groups) || !a.wpack16 || a.tiles_x != (a.W + 15) / 16 ||
+        a.tiles_y != (a.H + 15) / 16 || a.n_chunks < 1)
+        return hipErrorInvalidValue;
+    switch (nt) {
+        case 1: return c3h_launch_one<1>(a, n_groups, stream);
+        case 2: return c3h_launch_one<2>(a, n_groups, stream);
+        case 3: return c3h_launch_one<3>(a, n_groups, stream);
+        case 4: return c3h_launch_one<4>(a, n_groups, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dcscn

@@ -1,0 +1,313 @@
+// conv3_h: 3x3 SAME convolution + bias + activator (tf.nn.conv2d, helper/tf_graph.py:104-153) as a DIRECT implicit GEMM on
+// v_mfma_f32_16x16x32_f16 at f32 accuracy (split16.hpp: f16 (hi, lo) pieces, 3 products).
+//
+// Why direct form and not the Winograd domain of conv_wino2: at 1/16 of the f32 matrix cycles per MAC the 2.25x fewer
+// multiplies of F(2x2,3x3) no longer pay for what they cost around the MFMAs -- 16 frequencies x (hi, lo) filter fragments are
+// 4x the filter bytes per MAC (the kernel would be bound by L2 -> LDS traffic: ~50 B/clk/CU at full matrix rate against
+// ~58 available), and the input transform + split is 3.5 VALU per MFMA where 2 are free (profiles/r03_pipe_probe.txt).  The
+// direct form reads 0.28-0.33 LDS fragments per MFMA and splits every input value once per workgroup.
+//
+// GEMM view per tap: D[cout][pixel] += W_tap[cout][cin] * X[cin][pixel + tap offset]; A operand (rows) = filter fragment,
+// B operand (columns) = 16 consecutive pixels of one image row, so a lane ends up with 4 consecutive output channels of one
+// pixel = one float4 NHWC store (the C/D layout of the f16 instruction is the f32 one's).
+//
+// * workgroup = 4 waves = 16 x 16 pixels x NT*16 output channels; wave w owns rows 4w..4w+3 (four column tiles).
+// * K walks in chunks of 32 input channels.  The chunk's halo tile (18 x 18 pixels) is fetched into REGISTERS while the
+//   previous chunk computes (11 dwordx4 loads per thread, 8 adjacent lanes = the 128 contiguous bytes of a pixel), split into
+//   f16 (hi, lo) once, and written to LDS as the B-operand image: per pixel eight 16-byte units [kq][hi | lo] of 8 channels,
+//   position of unit (kq, part) in the pixel record = 2 * ((kq + (x >> 1)) & 3) + (part ^ (kq & 1)): the 16 lanes of every
+//   ds_read_b128 group then hit 16 different bank quads for all three tap columns (no padding: 41,472 bytes).  Halo pixels
+//   outside the image and channels past cin are written as zeros: that is the SAME padding.
+// * filters: f16 (hi, lo) A fragments packed by the host (split16_pack.hpp: pack_conv16) in read order, one tap = NT * 2 KB,
+//   a ring of three tap slots in LDS filled by LDS-DMA (conv_wino2.hpp: glds16) two taps ahead; the wait before a tap's barrier
+//   is a COUNTED vmcnt that leaves the next tap's pieces (and, early in a chunk, the input loads) in flight.
+//   One barrier per tap, two more per chunk around the write of the input image.  LDS = 41.5 + NT * 6 KB: two workgroups per CU.
+// * the chunk's input values are converted to (hi, lo) in registers a few per tap while the chunk's later taps compute (the
+//   f16 MFMA leaves two VALU issue slots per instruction free, profiles/r03_pipe_probe.txt); only the LDS writes sit between
+//   the two barriers of the chunk boundary.
+// * per tap and wave: 8 B-fragment reads + 2 NT A-fragment reads for 12 NT MFMAs (0.28 reads per MFMA at NT = 6).
+// * epilogue: accumulators * 2^-e, bias, activator, optional depth_to_space addressing, float4 stores; non-finite outputs
+//   raise redo[pixel tile] for the f32 kernel launched behind this one (split16.hpp).
+//
+#pragma once
+#include "conv_wino2.hpp"
+#include "split16.hpp"
+
+namespace dcscn {
+
+template <int NT>
+struct C3HGeom {
+    static constexpr int THREADS = 256;
+    static constexpr int KC = 32;
+    static constexpr int TH = 16, TW = 16;
+    static constexpr int HT = 18;                             // halo tile edge
+    static constexpr int HP = HT * HT;                        // 324 halo pixels
+    static constexpr int PIX_BYTES = 128;                     // 32 channels x (hi, lo) f16
+    static constexpr int ROW_BYTES = HT * PIX_BYTES;          // 2304
+    static constexpr int IN_BYTES = HP * PIX_BYTES;           // 41472
+    static constexpr int IN_ITEMS = HP * 8;                   // (pixel, channel quad) pieces of 16 bytes of f32
+    static constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;   // 11
+    static constexpr int F_TAP_BYTES = NT * 2048;             // [n][hi | lo][64 lanes][16 bytes]
+    static constexpr int F_PIECES = 2 * NT;                   // 1 KB DMA pieces of a tap
+    static constexpr int F_ROUNDS = (F_PIECES + 3) / 4;       // DMA instructions per wave and tap (waves without a piece of their own repeat one)
+    static constexpr int F_SLOTS = 3;
+    static constexpr int F_BASE = IN_BYTES;
+    static constexpr int LDS_BYTES = IN_BYTES + F_SLOTS * F_TAP_BYTES;
+};
+
+// position (16-byte unit) of channel group kq, piece `part` (0 hi, 1 lo) inside the record of halo column hx
+__host__ __device__ constexpr int c3h_unit(int hx, int kq, int part) { return (((kq + ((hx >> 1) & 3)) & 3) << 1) | (part ^ (kq & 1)); }
+
+// ABL (tuner only, tools/h16_tune.hip; results are wrong by design): 0 shipped; 1 no convert + write of the input image after the
+// first chunk; 2 nor its global loads; 3 no filter staging after the first tap; 4 no per-tap barrier; 5 one MFMA product of three;
+// 6 = 2 + 3 + 4 (LDS reads and MFMAs only)
+template <int NT, int NTV, int ABL = 0>
+__device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int tile_id, int ntile) {
+    using G = C3HGeom<NT>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15;
+    const int lk = lane >> 4;
+
+    int bid = tile_id;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int y0 = ty * G::TH;
+    const int x0 = tx * G::TW;
+    const int H = a.H, W = a.W;
+    const float* in_img = a.in + (size_t)img * H * W * a.in_stride + a.in_off;
+    // origin of the halo tile; only in-image addresses are ever dereferenced (out-of-image items read the tile's own first pixel)
+    const float* a_base = in_img + ((ptrdiff_t)(y0 - 1) * W + (x0 - 1)) * a.in_stride;
+
+    // ---- staging plan of the input image: item = r * 256 + tid = (halo pixel, channel quad) ----
+    const int cq = tid & 7;                                   // channel quad of every item of this thread
+    unsigned src_off[G::IN_ROUNDS];                           // byte offset from a_base (without the chunk's channel offset)
+    unsigned ok_mask = 0, col_bits = 0;                       // per item: inside the image; (halo column >> 1) & 3 (2 bits each)
+    static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
+        constexpr int r = decltype(r_)::value;
+        const int hp = r * 32 + (tid >> 3);
+        const int hrow = (hp * 3641) >> 16;                   // hp / 18 for hp < 324 + 32
+        const int hcol = hp - hrow * G::HT;
+        const int gy = y0 - 1 + hrow, gx = x0 - 1 + hcol;
+        const bool ok = hp < G::HP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        ok_mask |= ok ? (1u << r) : 0u;
+        src_off[r] = (unsigned)((ok ? (hrow * W + hcol) * a.in_stride : (W + 1) * a.in_stride) * 4);
+        col_bits |= (unsigned)((hcol >> 1) & 3) << (2 * r);
+    });
+    const bool all_in = __builtin_amdgcn_readfirstlane((int)(y0 >= 1 && x0 >= 1 && y0 + G::TH + 1 <= H && x0 + G::TW + 1 <= W)) != 0;   // no padding in this tile
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const char* f_base = reinterpret_cast<const char*>(a.wpack16) + (size_t)ntile * a.n_chunks * 9 * G::F_TAP_BYTES;   // wave-uniform
+    const unsigned f_off = (unsigned)(lane * 16);
+
+    f32x4 gin[G::IN_ROUNDS];
+    auto load_in = [&](int chunk) DCSCN_INL {
+        const int c0 = chunk * G::KC + cq * 4;
+        const unsigned coff = (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4);   // channels past cin: read something valid, written as zeros
+        // wave-uniform 64-bit base + 32-bit lane offset: the loads take the SGPR-base form, no 64-bit pointer per item is kept live
+        const char* base = reinterpret_cast<const char*>(a_base);
+        static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            gin[r] = *reinterpret_cast<const f32x4*>(base + (size_t)(src_off[r] + coff));
+        });
+    };
+    const float m1 = opaque_minus_one();
+    // item r of the chunk in flight: f32 values -> (hi, lo) pairs, in place (gin[r] = {hi01, hi23, lo01, lo23})
+    auto convert_in = [&](auto r_, int chunk) DCSCN_INL {
+        constexpr int r = decltype(r_)::value;
+        f32x4 x = gin[r];
+        const bool whole = all_in && (chunk + 1) * G::KC <= a.cin_phys;       // block uniform: nothing to zero
+        if (!whole) {
+            const bool ok = chunk * G::KC + cq * 4 < a.cin_phys && ((ok_mask >> r) & 1u);
+            x.x = ok ? x.x : 0.0f; x.y = ok ? x.y : 0.0f; x.z = ok ? x.z : 0.0f; x.w = ok ? x.w : 0.0f;
+        }
+        h4 hi, lo;
+        split4(x, m1, hi, lo);
+        const u32x2 hu = __builtin_bit_cast(u32x2, hi), lu = __builtin_bit_cast(u32x2, lo);
+        gin[r] = __builtin_bit_cast(f32x4, u32x4{hu.x, hu.y, lu.x, lu.y});
+    };
+    auto store_in = [&]() DCSCN_INL {
+        static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            const int hp = r * 32 + (tid >> 3);
+            const int kq = cq >> 1;
+            const int unit = (((kq + ((col_bits >> (2 * r)) & 3)) & 3) << 1) | (kq & 1);
+            const int off = hp * G::PIX_BYTES + unit * 16 + (cq & 1) * 8;
+            const u32x4 v = __builtin_bit_cast(u32x4, gin[r]);
+            if (r < G::IN_ROUNDS - 1 || hp < G::HP) {
+                *reinterpret_cast<u32x2*>(smem + off) = u32x2{v.x, v.y};
+                *reinterpret_cast<u32x2*>(smem + (off ^ 16)) = u32x2{v.z, v.w};
+            }
+        });
+    };
+    // filter pieces of global tap g = chunk * 9 + tap -> ring slot g % 3
+    auto dma_f = [&](int g, int slot) DCSCN_INL {
+        static_for<0, G::F_ROUNDS>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            const int piece = (wave + 4 * r) % G::F_PIECES;
+            glds16(f_base + (size_t)g * G::F_TAP_BYTES + piece * 1024, f_off, lds0 + G::F_BASE + slot * G::F_TAP_BYTES + (unsigned)piece * 1024u);
+        });
+    };
+
+    f32x4 acc[4][NTV];
+    static_for<0, 4>([&](auto m_) DCSCN_INL {
+        static_for<0, NTV>([&](auto n_) DCSCN_INL { acc[decltype(m_)::value][decltype(n_)::value] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; });
+    });
+
+    // B fragment addresses: pixel (row 4w + m + ky, column lj + kx) of the halo tile, channel group lk; one base per tap column
+    int b_hi[3];
+    static_for<0, 3>([&](auto kx_) DCSCN_INL {
+        constexpr int kx = decltype(kx_)::value;
+        const int hx = lj + kx;
+        b_hi[kx] = (4 * wave * G::HT + hx) * G::PIX_BYTES + c3h_unit(hx, lk, 0) * 16;
+    });
+    const int a_lane = G::F_BASE + lane * 16;
+
+    const int n_chunks = a.n_chunks;
+    const int n_taps = n_chunks * 9;
+    dma_f(0, 0);
+    dma_f(1, 1);                                              // n_taps >= 9
+    load_in(0);
+    static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL { convert_in(r_, 0); });
+    store_in();
+    // K loop.  Per tap: wait for this tap's filter pieces (counted: the next tap's stay in flight), barrier, refill the slot the
+    // previous tap was read from with the tap after next, compute.  vmcnt retires in order, so a filter wait also waits for every
+    // older operation: the chunk's 11 input loads are issued at tap 0 BEHIND that tap's DMA and are first forced by the wait of
+    // tap 3 (three taps = ~2.5 k cycles after issue); the waits of taps 1 and 2 count them as in flight.
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const bool more = chunk + 1 < n_chunks;                // block uniform
+        static_for<0, 9>([&](auto t_) DCSCN_INL {
+            constexpr int tap = decltype(t_)::value;
+            constexpr int ky = tap / 3, kx = tap % 3;
+            constexpr int slot = tap % 3;                      // (chunk * 9 + tap) % 3
+            const int g = chunk * 9 + tap;
+            if constexpr (ABL != 3 && ABL != 6) {
+                if constexpr (tap == 1 || tap == 2) {
+                    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS + G::IN_ROUNDS) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS) : "memory");
+                }
+            }
+            if constexpr ((ABL != 4 && ABL != 6) || tap == 0) __syncthreads();
+            if constexpr (ABL != 3 && ABL != 6) {
+                // always the same number of operations per wave (the counts above rely on it): past the last tap the last one is re-fetched
+                dma_f(g + 2 < n_taps ? g + 2 : n_taps - 1, (tap + 2) % 3);
+            }
+            if constexpr (tap == 0 && ABL != 2 && ABL != 6) { if (more) load_in(chunk + 1); }
+            h8 xh[4], xl[4];
+            static_for<0, 4>([&](auto m_) DCSCN_INL {
+                constexpr int m = decltype(m_)::value;
+                xh[m] = *reinterpret_cast<const h8*>(smem + b_hi[kx] + (m + ky) * G::ROW_BYTES);
+                xl[m] = *reinterpret_cast<const h8*>(smem + (b_hi[kx] ^ 16) + (m + ky) * G::ROW_BYTES);
+            });
+            const char* fs = smem + a_lane + slot * G::F_TAP_BYTES;
+            static_for<0, NTV>([&](auto n_) DCSCN_INL {
+                constexpr int n = decltype(n_)::value;
+                const h8 wh = *reinterpret_cast<const h8*>(fs + (2 * n) * 1024);
+                const h8 wl = *reinterpret_cast<const h8*>(fs + (2 * n + 1) * 1024);
+                static_for<0, 4>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    if constexpr (ABL != 5) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[m], acc[m][n], 0, 0, 0);
+                    }
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[m], acc[m][n], 0, 0, 0);
+                });
+            });
+            // the next chunk's input values become (hi, lo) pairs two items per tap from tap 3 on (their loads are 3+ taps old)
+            if constexpr (tap >= 3 && ABL != 1 && ABL != 2 && ABL != 6) {
+                if (more) {
+                    static_for<2 * (tap - 3), (2 * (tap - 3) + 2 < G::IN_ROUNDS ? 2 * (tap - 3) + 2 : G::IN_ROUNDS)>([&](auto r_) DCSCN_INL { convert_in(r_, chunk + 1); });
+                }
+            }
+        });
+        if constexpr (ABL != 1 && ABL != 2 && ABL != 6) {
+            if (more) {
+                __syncthreads();                              // every wave is past its last read of this chunk's image
+                store_in();                                   // made visible by the barrier in front of the next tap
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the clamped re-fetches of the last two taps
+
+    // ---- epilogue ----
+    const int cbase = ntile * NT * 16 + 4 * lk;                                  // bias / slope index: padded group layout
+    const int obase = cbase - 16 * (ntile > a.n_full ? ntile - a.n_full : 0);    // conv channel: groups past n_full are one tile narrower
+    const int act = a.act;
+    const int ps = a.ps;
+    const int orow = W * ps;
+    const float inv = a.inv_scale;
+    const float zero = opaque_zero();
+    float chk = 0.0f;
+    const int gx = x0 + lj;
+    auto finish = [&](auto act_c) DCSCN_INL {
+        constexpr int ACT_C = decltype(act_c)::value;
+        const int act_e = ACT_C >= 0 ? ACT_C : act;
+        static_for<0, NTV>([&](auto n_) DCSCN_INL {
+            constexpr int n = decltype(n_)::value;
+            const int c = obase + n * 16;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + cbase + n * 16);
+            f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (act_e == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(a.alpha + cbase + n * 16);
+            const bool first = c < a.split;
+            float* optr = first ? a.out0.ptr : a.out1.ptr;
+            const int ostride = first ? a.out0.stride : a.out1.stride;
+            const int ooff = first ? a.out0.off : a.out1.off;
+            const int owidth = first ? a.out0.width : a.out1.width;
+            const int cc = first ? c : c - a.split;
+            int ch = cc, ay = 0, bx = 0;
+            if (ps != 1) {                                         // depth_to_space: channel (ay*ps + bx)*ps_c + ch
+                const int sub = cc / a.ps_c;
+                ch = cc - sub * a.ps_c;
+                ay = sub / ps;
+                bx = sub - ay * ps;
+            }
+            const bool live = gx < W && cc < owidth;
+            static_for<0, 4>([&](auto m_) DCSCN_INL {
+                constexpr int m = decltype(m_)::value;
+                const int gy = y0 + 4 * wave + m;
+                f32x4 v = acc[m][n] * inv + bv;
+                v.x = activate1(v.x, av.x, act_e);
+                v.y = activate1(v.y, av.y, act_e);
+                v.z = activate1(v.z, av.z, act_e);
+                v.w = activate1(v.w, av.w, act_e);
+                if (live && gy < H) {
+                    chk = nonfinite_acc(chk, acc[m][n], zero);
+                    const size_t pix = (size_t)((img * H + gy) * ps + ay) * orow + (size_t)(gx * ps + bx);
+                    if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + pix * a.res_stride + ch);
+                    *reinterpret_cast<f32x4*>(optr + pix * ostride + ooff + ch) = v;
+                }
+            });
+        });
+    };
+    if (act == ACT_ALPHA) finish(std::integral_constant<int, ACT_ALPHA>{});
+    else if (act == ACT_NONE) finish(std::integral_constant<int, ACT_NONE>{});
+    else finish(std::integral_constant<int, -1>{});
+    if (chk != chk && a.redo) a.redo[tile_id] = 1;
+}
+
+// 1-D grid decoded as conv_wino2's: the channel groups of one pixel tile get ids that are congruent mod 8 and close together
+// (same XCD, about the same time: the input tile is shared through that XCD's L2)
+template <int NT, int WPS = 2, int ABL = 0>
+__global__ __launch_bounds__(256, WPS) void conv3_h(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c3h[];
+    const int Gn = a.n_groups, S = a.group_span;
+    const int tiles8 = (a.N * a.tiles_y * a.tiles_x + 7) >> 3;
+    int id = blockIdx.x;
+    const int phase_ids = tiles8 * 8 * S;
+    const int phase = id / phase_ids;
+    id -= phase * phase_ids;
+    const int gs = (Gn - phase * S) < S ? (Gn - phase * S) : S;
+    const int q = id / (8 * gs), r = id - q * 8 * gs;
+    if (q >= tiles8) return;
+    const int ntile = phase * S + (r >> 3);
+    const int tile_id = q * 8 + (r & 7);
+    if (tile_id >= a.N * a.tiles_y * a.tiles_x) return;
+    if (ntile < a.n_full) conv3_h_body<NT, NT, ABL>(a, smem_c3h, tile_id, ntile);                 // block uniform
+    else if constexpr (NT >= 2) conv3_h_body<NT, NT - 1, ABL>(a, smem_c3h, tile_id, ntile);
+}
+
+}  // namespace dcscn

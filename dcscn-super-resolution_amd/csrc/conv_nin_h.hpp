@@ -1,47 +1,46 @@
-// conv_nin_h: conv_nin (the wide 1x1 convs A1 || B1 over the skip-concat, DCSCN.py:273-277, and the non-NIN "C" layer) with
-// the contraction on the 16-bit matrix pipe at f32 accuracy (split16.hpp): v_mfma_f32_16x16x16_f16 x 3 products instead of
-// four v_mfma_f32_16x16x4_f32 per 16-channel chunk.  Everything around the MFMAs is conv_nin's pipeline, unchanged:
+// conv_nin_h: the wide 1x1 convs (A1 || B1 over the skip-concat, DCSCN.py:273-277; the non-NIN "C" layer) on
+// v_mfma_f32_16x16x32_f16 at f32 accuracy (split16.hpp) -- the conv_nin pipeline with 32-channel chunks, so that the matrix instruction
+// is the full-rate K = 32 form (v_mfma_f32_16x16x16_f16 takes the same 16 cycles for half the work: profiles/r03_pipe_probe.txt).
 //
-// * 256 consecutive pixels of the flat pixel list per workgroup, wave w owns 64 of them (four MFMA column tiles) for all
-//   NT*16 <= 96 output channels of the group; 16-channel chunks; input [256 pixels][64 bytes] by LDS-DMA (four adjacent
-//   lanes fetch the 64 contiguous bytes of a pixel's chunk, or of one source quad each with MULTI), two input stages with the
-//   fragments of chunk c+1 read while chunk c computes, one barrier per chunk.
-// * the B operand of the 16x16x16 instruction is exactly the ds_read_b128 fragment of before -- lane (j, kq) holds channels
-//   4kq..4kq+3 of pixel j -- split into (hi, lo) in registers: 6 VALU per fragment, 24 per chunk and wave, once per value.
-// * filters: [chunk][tile n][lane][hi0..3 | lo0..3] halfs (split16_pack.hpp: pack_nin16) = ONE ds_read_b128 per lane and tile
-//   for both pieces; NT KB per chunk instead of 7 KB of f32.
-// * epilogue: accumulators * 2^-e (the filter scale), bias, activator, two destinations, float4 stores -- plus the non-finite
-//   check that raises redo[pixel block] for the f32 kernel behind this one (split16.hpp).
-//
-// With the matrix time down 5x the launch is bound by reading the 5.3 KB of concat per pixel from HBM.
+// * 128 consecutive pixels of the flat pixel list per workgroup, wave w owns 32 of them (two MFMA column tiles) for all
+//   NT*16 <= 96 output channels of the group.  Two workgroups per CU.
+// * input stage = [128 pixels][8 slots of 16 bytes]: the chunk's 32 channels of each pixel, 128 contiguous bytes fetched by eight
+//   adjacent lanes of an LDS-DMA (or one source quad each with MULTI).  Slot order inside a pixel record is swizzled on the SOURCE
+//   side (the DMA destination is lane-linear): quad q = 2 kq + half sits at slot 2 * ((kq + (p >> 1)) & 3) + (half ^ (kq & 1)), which
+//   makes both ds_read_b128 of a B fragment (lane (j, kq): channels 8kq..8kq+3, then 8kq+4..8kq+7 of pixel j) conflict free.
+// * S input stages (2 or 3): chunk c + S is fetched while chunk c computes; fragments of chunk c + 1 are read during chunk c;
+//   a chunk's filter pieces are issued before its input pieces so that the counted vmcnt wait covers them.
+// * filters: pack_conv16 image with one tap: [chunk][n][hi | lo][lane][8 halfs], 2 NT KB per chunk, two stages.
+// * epilogue as conv_nin plus the split16 parts (scale 2^-e, bias, activator, two destinations, redo flag per 256-pixel block = blockIdx.x / 2).
 #pragma once
 #include "conv_nin.hpp"
 #include "split16.hpp"
 
 namespace dcscn {
 
-template <int NT>
+template <int NT, int S = 2>
 struct NinHGeom {
     static constexpr int THREADS = 256;
-    static constexpr int KC = 16;
-    static constexpr int PIX = 256;
-    static constexpr int MT = 4;
-    static constexpr int PSTRIDE = 64;
-    static constexpr int A_SLOTS = PIX * 4;
-    static constexpr int A_DMA = A_SLOTS / 64;
+    static constexpr int KC = 32;
+    static constexpr int PIX = 128;
+    static constexpr int MT = 2;
+    static constexpr int PSTRIDE = 128;
+    static constexpr int A_SLOTS = PIX * 8;
+    static constexpr int A_DMA = A_SLOTS / 64;                // 16 wave instructions, 4 per wave
     static constexpr int A_BYTES = A_SLOTS * 16;              // 16384
     static constexpr int A_ROUNDS = A_DMA / 4;
-    static constexpr int B_BYTES = NT * 1024;                 // [n][64 lanes][16 bytes]
-    static constexpr int B_PIECES = NT;
+    static constexpr int B_BYTES = NT * 2048;
+    static constexpr int B_PIECES = 2 * NT;
     static constexpr int B_ROUNDS = (B_PIECES + 3) / 4;
     static constexpr int B_STAGE = B_BYTES;
-    static constexpr int B_BASE = 2 * A_BYTES;
-    static constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_STAGE;
+    static constexpr int B_BASE = S * A_BYTES;
+    static constexpr int LDS_BYTES = S * A_BYTES + 2 * B_STAGE;
+    static_assert(S == 2 || S == 3, "2 or 3 input stages");
 };
 
-template <int NT, int NTV, bool MULTI>
+template <int NT, int NTV, bool MULTI, int S>
 __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, long long pix0, int ntile) {
-    using G = NinHGeom<NT>;
+    using G = NinHGeom<NT, S>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -50,18 +49,21 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
     const long long npix = (long long)a.N * a.H * a.W;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)smem;
 
-    // ---- DMA sources (conv_nin.hpp): piece p = wave + 4r covers slots [64p, 64p + 64); slot = 4 * pixel + quad ----
+    // ---- DMA sources: piece p = wave + 4r covers slots [64p, 64p + 64) = pixels [8p, 8p + 8); this lane's slot position
+    // (lane & 7) of pixel 8p + (lane >> 3) holds channel quad dq (the inverse of the slot swizzle; (pixel >> 1) & 3 == (lane >> 4) & 3) ----
+    const int d_kq = (((lane & 7) >> 1) - ((lane >> 4) & 3)) & 3;
+    const int dq = 2 * d_kq + ((lane & 1) ^ (d_kq & 1));
+    // Every lane ALWAYS issues its piece (the counted vmcnt wait of the K loop needs a fixed number of operations per wave):
+    // pixels past the end of the list re-read the last pixel (their columns are never stored), channel quads past cin re-read
+    // quad 0 (their filter rows are zero, the data is finite), invalid table entries point at valid memory with stride 0.
     unsigned a_off[G::A_ROUNDS];
-    bool a_on[G::A_ROUNDS];
-    int a_q[G::A_ROUNDS];
+    long long a_pix[G::A_ROUNDS];
     static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
-        const int slot = (wave + 4 * r) * 64 + lane;
-        const int p = slot >> 2;
-        const int q = slot & 3;
-        a_q[r] = 4 * q;
-        a_on[r] = pix0 + p < npix;
-        a_off[r] = (unsigned)((p * a.in_stride + 4 * q) * 4);
+        long long p = pix0 + (wave + 4 * r) * 8 + (lane >> 3);
+        p = p < npix ? p : npix - 1;
+        a_pix[r] = p;
+        a_off[r] = (unsigned)((p - pix0) * a.in_stride * 4);
     });
     const float* a_base = a.in + (size_t)pix0 * a.in_stride + a.in_off;                           // wave-uniform
     const char* b_base = reinterpret_cast<const char*>(a.wpack16) + (size_t)ntile * a.n_chunks * G::B_BYTES;
@@ -69,33 +71,28 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
 
     auto dma_b = [&](auto r_, int chunk, unsigned stage) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
-        const int piece = wave + 4 * r;
-        if (piece < G::B_PIECES)                              // wave-uniform
-            glds16(b_base + (size_t)chunk * G::B_BYTES + 1024 * piece, b_off, lds0 + G::B_BASE + stage * G::B_STAGE + (unsigned)piece * 1024u);
+        const int piece = (wave + 4 * r) % G::B_PIECES;       // waves without a piece of their own repeat one: same count for every wave
+        glds16(b_base + (size_t)chunk * G::B_BYTES + 1024 * piece, b_off, lds0 + G::B_BASE + stage * G::B_STAGE + (unsigned)piece * 1024u);
     };
     typedef const volatile __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
     u32x4 ent = {0u, 0u, 0u, 0u};
     auto load_ent = [&](int chunk) DCSCN_INL {
-        if constexpr (MULTI) ent = *(lds_u32x4_ptr)(uintptr_t)(lds0 + G::LDS_BYTES + (unsigned)(chunk * 4 + (lane & 3)) * 16u);
+        if constexpr (MULTI) ent = *(lds_u32x4_ptr)(uintptr_t)(lds0 + G::LDS_BYTES + (unsigned)(chunk * 8 + dq) * 16u);
     };
     auto dma_a = [&](auto r_, int chunk, unsigned stage) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
         if constexpr (MULTI) {
-            const unsigned long long pix = (unsigned long long)(pix0 + (wave + 4 * r) * 16 + (lane >> 2));
-            const char* src = reinterpret_cast<const char*>(((unsigned long long)ent.y << 32) | ent.x) + pix * ent.z;
-            if (a_on[r] && ent.w) glds16v(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
+            const char* src = reinterpret_cast<const char*>(((unsigned long long)ent.y << 32) | ent.x) + (unsigned long long)a_pix[r] * ent.z;
+            glds16v(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
         } else {
-            if (a_on[r] && chunk * G::KC + a_q[r] < a.cin_phys)
-                glds16(a_base + chunk * G::KC, a_off[r], lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
+            const int c0 = chunk * G::KC + 4 * dq;
+            glds16(a_base, a_off[r] + (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4), lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
         }
     };
 
-    // clear both input stages once: channel-tail slots are never written, and 0 * stale must not be 0 * NaN
     {
-        const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = tid; i < 2 * G::A_BYTES / 16; i += G::THREADS) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + 16 * i) = z;
         if constexpr (MULTI)
-            for (int i = tid; i < 4 * a.n_chunks; i += G::THREADS)
+            for (int i = tid; i < 8 * a.n_chunks; i += G::THREADS)
                 *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::LDS_BYTES + 16 * i) = reinterpret_cast<const f32x4*>(a.srctab)[i];
         __syncthreads();
     }
@@ -105,7 +102,9 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
         static_for<0, NTV>([&](auto n_) DCSCN_INL { acc[decltype(m_)::value][decltype(n_)::value] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; });
     });
 
-    const unsigned a_lane = lds0 + (unsigned)((64 * wave + lj) * G::PSTRIDE + lk * 16);
+    // B fragment of pixel tile m: pixel 32 * wave + 16 * m + lj, channel group lk: halves at slot 2 * ((lk + (pixel >> 1)) & 3) + (lk & 1), ^ 1
+    const unsigned a_rel = (unsigned)((32 * wave + lj) * G::PSTRIDE + ((((lk + (lj >> 1)) & 3) << 1) | (lk & 1)) * 16);
+    const unsigned a_lane = lds0 + a_rel, a_lane2 = lds0 + (a_rel ^ 16u);
     const unsigned b_lane = lds0 + (unsigned)(G::B_BASE + lane * 16);
     typedef const volatile __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
     typedef const volatile __attribute__((address_space(3))) h8* lds_h8_ptr;
@@ -114,57 +113,60 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
     const int last = a.n_chunks - 1;
     static_for<0, G::B_ROUNDS>([&](auto r_) DCSCN_INL { dma_b(r_, 0, 0); });
     load_ent(0);
-    static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL { dma_a(r_, 0, 0); });
-    load_ent(last < 1 ? last : 1);
-    static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL { dma_a(r_, last < 1 ? last : 1, 1); });
-    load_ent(last < 2 ? last : 2);
+    static_for<0, S>([&](auto st_) DCSCN_INL {                // chunks 0 .. S-1 into stages 0 .. S-1
+        constexpr int st = decltype(st_)::value;
+        static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL { dma_a(r_, last < st ? last : st, st); });
+        load_ent(last < st + 1 ? last : st + 1);
+    });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    f32x4 xv[G::MT];
+    f32x4 xa[G::MT], xb[G::MT];
     static_for<0, G::MT>([&](auto m_) DCSCN_INL {
         constexpr int m = decltype(m_)::value;
-        xv[m] = *(lds_f32x4_ptr)(uintptr_t)(a_lane + m * 16 * G::PSTRIDE);
+        xa[m] = *(lds_f32x4_ptr)(uintptr_t)(a_lane + m * 16 * G::PSTRIDE);
+        xb[m] = *(lds_f32x4_ptr)(uintptr_t)(a_lane2 + m * 16 * G::PSTRIDE);
     });
     __syncthreads();                                          // every wave holds its fragments of chunk 0: input stage 0 may be refilled
+    unsigned sa = 0;                                          // chunk % S
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
         const unsigned sb = chunk & 1;
         const int cb = chunk + 1 < last ? chunk + 1 : last;   // filters to fetch (clamped: redundant copies land in a dead stage)
-        const int ca = chunk + 2 < last ? chunk + 2 : last;   // input to fetch
+        const int ca = chunk + S < last ? chunk + S : last;   // input to fetch
+        const unsigned sn = sa + 1 == S ? 0 : sa + 1;
         const unsigned Bs = b_lane + sb * G::B_STAGE;
-        const unsigned An = a_lane + (sb ^ 1) * G::A_BYTES;
-        h4 wh[NTV], wl[NTV];
-        static_for<0, NTV>([&](auto n_) DCSCN_INL {
-            constexpr int n = decltype(n_)::value;
-            const h8 w = *(lds_h8_ptr)(uintptr_t)(Bs + n * 1024);
-            wh[n] = __builtin_shufflevector(w, w, 0, 1, 2, 3);
-            wl[n] = __builtin_shufflevector(w, w, 4, 5, 6, 7);
-        });
-        f32x4 xn[G::MT];
+        const unsigned An = a_lane + sn * G::A_BYTES, An2 = a_lane2 + sn * G::A_BYTES;
+        // filters first, then input: the counted wait below relies on this order
+        static_for<0, G::B_ROUNDS>([&](auto r_) DCSCN_INL { dma_b(r_, cb, sb ^ 1); });
+        f32x4 na[G::MT], nb[G::MT];
         static_for<0, G::MT>([&](auto m_) DCSCN_INL {
             constexpr int m = decltype(m_)::value;
-            h4 xh, xl;
-            split4(xv[m], m1, xh, xl);
+            h8 xh, xl;
+            split8(xa[m], xb[m], m1, xh, xl);
             static_for<0, NTV>([&](auto n_) DCSCN_INL {
                 constexpr int n = decltype(n_)::value;
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl[n], xh, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[n], xl, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh[n], xh, acc[m][n], 0, 0, 0);
+                const h8 wh = *(lds_h8_ptr)(uintptr_t)(Bs + (2 * n) * 1024);
+                const h8 wl = *(lds_h8_ptr)(uintptr_t)(Bs + (2 * n + 1) * 1024);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[m][n], 0, 0, 0);
+                // the chunk's input pieces behind the first MFMA groups
+                if constexpr (m * NTV + n < G::A_ROUNDS) dma_a(std::integral_constant<int, m * NTV + n>{}, ca, sa);
             });
-            // the chunk's DMA pieces behind the MFMA groups; the next chunk's fragments right after
-            static_for<0, G::B_ROUNDS + G::A_ROUNDS>([&](auto i_) DCSCN_INL {
-                constexpr int i = decltype(i_)::value;
-                if constexpr (i % G::MT == m) {
-                    if constexpr (i < G::B_ROUNDS) dma_b(std::integral_constant<int, i>{}, cb, sb ^ 1);
-                    else dma_a(std::integral_constant<int, i - G::B_ROUNDS>{}, ca, sb);
-                }
-            });
-            xn[m] = *(lds_f32x4_ptr)(uintptr_t)(An + m * 16 * G::PSTRIDE);
+            if constexpr (m == G::MT - 1 && G::MT * NTV < G::A_ROUNDS)
+                static_for<G::MT * NTV, G::A_ROUNDS>([&](auto r_) DCSCN_INL { dma_a(r_, ca, sa); });
+            na[m] = *(lds_f32x4_ptr)(uintptr_t)(An + m * 16 * G::PSTRIDE);
+            nb[m] = *(lds_f32x4_ptr)(uintptr_t)(An2 + m * 16 * G::PSTRIDE);
         });
-        load_ent(chunk + 3 < last ? chunk + 3 : last);      // the next iteration's ca
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        load_ent(chunk + S + 1 < last ? chunk + S + 1 : last);      // the next iteration's ca
+        // the next chunk reads the fragments of chunk c + 2 and the filters of chunk c + 1: with S = 3 only this iteration's
+        // input pieces (the youngest A_ROUNDS operations) may stay in flight
+        if constexpr (S == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::A_ROUNDS) : "memory");
         __syncthreads();
-        static_for<0, G::MT>([&](auto m_) DCSCN_INL { xv[decltype(m_)::value] = xn[decltype(m_)::value]; });
+        static_for<0, G::MT>([&](auto m_) DCSCN_INL { xa[decltype(m_)::value] = na[decltype(m_)::value]; xb[decltype(m_)::value] = nb[decltype(m_)::value]; });
+        sa = sn;
     }
+    if constexpr (S > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: un-scale, bias, activator, store (float4 per lane: channels cbase..cbase+3 of one pixel) ----
     const int cbase = ntile * NT * 16 + 4 * lk;
@@ -191,7 +193,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
             if (cc < owidth) {
                 static_for<0, G::MT>([&](auto m_) DCSCN_INL {
                     constexpr int m = decltype(m_)::value;
-                    const long long p = pix0 + 64 * wave + 16 * m + lj;
+                    const long long p = pix0 + 32 * wave + 16 * m + lj;
                     f32x4 v = acc[m][n] * inv + bv;
                     v.x = activate1(v.x, av.x, act_e);
                     v.y = activate1(v.y, av.y, act_e);
@@ -208,17 +210,17 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
     if (act == ACT_ALPHA) finish(std::integral_constant<int, ACT_ALPHA>{});
     else if (act == ACT_NONE) finish(std::integral_constant<int, ACT_NONE>{});
     else finish(std::integral_constant<int, -1>{});
-    if (chk != chk && a.redo) a.redo[blockIdx.x] = 1;          // any lane, any group of the block: same value, benign race
+    if (chk != chk && a.redo) a.redo[blockIdx.x >> 1] = 1;     // the f32 kernel's unit is a block of 256 pixels
 }
 
-// grid = (pixel blocks of 256, channel groups)
-template <int NT, bool MULTI = false, int WPS = 3>
+// grid = (pixel blocks of 128, channel groups)
+template <int NT, bool MULTI = false, int S = 2, int WPS = 2>
 __global__ __launch_bounds__(256, WPS) void conv_nin_h(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const long long pix0 = (long long)blockIdx.x * NinHGeom<NT>::PIX;
+    const long long pix0 = (long long)blockIdx.x * NinHGeom<NT, S>::PIX;
     const int ntile = blockIdx.y;
-    if (ntile < a.n_full) conv_nin_h_body<NT, NT, MULTI>(a, smem, pix0, ntile);          // block uniform
-    else if constexpr (NT >= 2) conv_nin_h_body<NT, NT - 1, MULTI>(a, smem, pix0, ntile);
+    if (ntile < a.n_full) conv_nin_h_body<NT, NT, MULTI, S>(a, smem, pix0, ntile);          // block uniform
+    else if constexpr (NT >= 2) conv_nin_h_body<NT, NT - 1, MULTI, S>(a, smem, pix0, ntile);
 }
 
 }  // namespace dcscn

@@ -100,9 +100,19 @@ constexpr int kNinKC = 16;
 constexpr int kNinMaxNT = 6;
 hipError_t nin_init_kernels();
 hipError_t nin_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
-// the same on the f16 matrix pipe (conv_nin_h.hpp); args.wpack16 = pack_nin16 image, args.inv_scale, args.redo
+// ---- split16 kernels (split16.hpp): f32-accurate contractions on the f16 matrix pipe ----
+// conv_nin_h.hpp: conv_nin's job with 32-channel chunks on v_mfma_f32_16x16x32_f16; args.wpack16 = pack_conv16 image with one tap
+// (groups as for nin_launch), args.n_chunks = ceil(cin_phys / 32), args.inv_scale, args.redo (one flag per 256 pixels);
+// a multi-source table holds 8 entries per chunk and every entry points at readable memory (invalid ones with stride 0).
+constexpr int kNinHKC = 32;
 hipError_t nin_h_init_kernels();
 hipError_t nin_h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
+// conv3_h.hpp: 3x3 conv + bias + activator (+ depth_to_space) as a direct implicit GEMM; `nt` tiles per group (1..4), groups as for
+// wino_launch; args.wpack16 = pack_conv16 image with 9 taps, args.n_chunks = ceil(cin_phys / 32), args.redo (one flag per 16x16 tile)
+constexpr int kC3hKC = 32;
+constexpr int kC3hMaxNT = 4;
+hipError_t c3h_init_kernels();
+hipError_t c3h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
 
 // ---- row-streamed feature extractor of the separable narrow nets (feat_stream.hpp) ----
 constexpr int kStreamPX = 48;                  // computed columns per strip: three 16-pixel MFMA tiles

@@ -28,6 +28,8 @@ hipError_t conv_init_kernels() {
     if (e == hipSuccess) e = conv_init_k7();
     if (e == hipSuccess) e = wino_init_kernels();
     if (e == hipSuccess) e = nin_init_kernels();
+    if (e == hipSuccess) e = nin_h_init_kernels();
+    if (e == hipSuccess) e = c3h_init_kernels();
     if (e == hipSuccess) stream_init_kernels();
     return e;
 }

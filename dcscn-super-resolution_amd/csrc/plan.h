@@ -1,0 +1,230 @@
+// Internal interface of the plan / ABI layer: the handle, the launch plan (Op) and the functions its translation units share.
+//   graph.hip  build_graph (DCSCN.py:222-325 as a list of launches), graph rewrites (folded tail, streamed nets, dense features)
+//   pack.hip   filter repacking into the LDS images of the kernels (finalize_op and the streamed-kernel blobs)
+//   exec.hip   workspace, launches, sub-batching, spatial tiling, resize
+//   api.hip    the extern "C" surface of include/dcscn.h
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dcscn.h"
+#include "kernels.h"
+
+namespace dcscn_impl {
+using namespace dcscn;
+
+inline int pad4(int c) { return (c + 3) & ~3; }
+inline int pad16(int c) { return (c + 15) & ~15; }
+
+enum { EXT_X = -1, EXT_X2 = -2, EXT_Y = -3 };
+enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2, OP_COUT1 = 3, OP_STREAM = 4, OP_TAIL = 5 };
+
+struct TensorSpec {
+    std::string name;
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool set = false;
+};
+
+struct WsBuf {
+    int stride = 0;       // floats per pixel
+    int res = 1;          // pixels per LR pixel along one axis
+    size_t offset = 0;    // byte offset inside the arena for the current layout
+};
+
+// one source block of a launch's filter matrix: conv channels [dst, dst + cout) come from `w`
+struct ColSeg {
+    int w = -1, b = -1, alpha = -1;   // tensor indices (-1 = absent)
+    int cout = 0;                     // output channels taken from the tensors ...
+    int col0 = 0;                     // ... starting at this one (a layer split over two launches)
+    int dst = 0;
+    int dw1 = -1;                     // 1x1 depthwise filter [1, 1, cin, 1] of a separable 1x1 conv, folded into the
+                                      // pointwise weights when they are packed: sum_c (x_c d_c) p_co = sum_c x_c (d_c p_co)
+};
+
+struct Op {
+    OpKind kind = OP_CONV;
+    std::string name;
+    int ks = 3, cin = 0, cout = 0, res = 1;
+    int act = ACT_NONE;
+    float const_alpha = 0.0f;       // relu / leaky_relu slope when there is no alpha tensor
+    // input
+    int in_buf = EXT_X, in_off = 0, cin_phys = 0;
+    int in_stride_override = 0;     // > 0: pixel stride of the input differs from its buffer's
+    std::vector<int> chan_map;      // logical input channel -> physical channel relative to in_off
+    // filter sources
+    std::vector<ColSeg> segs;
+    int dw_w = -1;                  // depthwise filter tensor (OP_DW, fused-depthwise OP_CONV, OP_COUT1 of a separable conv)
+    int dwk = 0;                    // fused depthwise kernel size of an OP_CONV (0 = plain conv)
+    float out_scale = 1.0f;         // OP_COUT1: pointwise scalar of a separable 1->1 conv
+    int tconv_s = 0;                // > 0: the op is tf.nn.conv2d_transpose with this stride, run as its
+                                    // equivalent 3x3 conv to s*s*C channels + depth_to_space (see add_tconv)
+    int fold_s = 0;                 // > 0: folded linear tail (see fold_linear_tail): pixel-shuffler block
+    int fold_c = 0;                 //      channels after depth_to_space
+    int fold_rw = -1;               //      filter tensor of the last reconstruction conv [3, 3, C, 1]
+    // output
+    int out_buf[2] = {EXT_Y, EXT_Y}, out_off[2] = {0, 0}, out_width[2] = {0, 0};
+    int split = 1 << 30;
+    int ps = 1, ps_c = 0;
+    bool residual = false;
+    bool vec4 = true;
+    // conv_igemm variant
+    ConvShape shape{3, 2, 1, 4};
+    int n_tiles = 1, n_chunks = 0, ctot = 0;
+    int n_full = 0;                 // Winograd: groups [0, n_full) hold shape.nt channel tiles, the others shape.nt - 1
+    // accounting
+    int64_t macs = 0, bytes = 0;
+    // device copies
+    float* d_w = nullptr;
+    float* d_bias = nullptr;
+    float* d_alpha = nullptr;
+    int32_t* d_map = nullptr;
+    float* d_dww = nullptr;
+    // multi-source input (densify_features): the K axis is the concatenation of these dense tensors
+    std::vector<std::pair<int, int>> multi;   // (buffer, physical channels = pad4)
+    std::vector<NinSrcQuad> h_srctab;         // host copy of the quad table, refilled whenever the arena is re-carved
+    NinSrcQuad* d_srctab = nullptr;
+    // OP_STREAM (stream_features): the launches this op replaces, kept for their tensor indices, and the kernel plan
+    std::vector<Op> fused;
+    StreamArgs stream{};
+    TailArgs tail{};
+    int halo = -1;                            // >= 0: receptive-field radius of the op in ITS pixels (else ks / 2)
+    // split16 variant of the launch (split16.hpp: the contraction on the f16 matrix pipe at f32 accuracy), taken when the handle's
+    // "split16" option is on; the f32 launch then runs behind it as the fallback of the units it flags
+    struct Split16 {
+        bool on = false;
+        int nt = 0, n_tiles = 0, n_full = 0, n_chunks = 0;   // channel groups (conv3_h: its own plan; conv_nin_h: the f32 launch's) and 32-channel chunks
+        float inv_scale = 1.0f;                   // 2^-e of the filter scale
+        void* d_w = nullptr;                      // pack_conv16 image
+        float* d_bias = nullptr;                  // conv3_h: bias / slope in ITS padded group layout (conv_nin_h shares the f32 launch's)
+        float* d_alpha = nullptr;
+        size_t redo_off = 0;                      // first flag of the op among the pass's redo flags (ensure_workspace)
+    } h16;
+};
+
+}  // namespace dcscn_impl
+
+using namespace dcscn_impl;
+
+struct dcscn_ctx {
+    dcscn_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    bool finalized = false;
+
+    std::vector<int> sched;
+    std::vector<TensorSpec> tensors;
+    std::map<std::string, int> tensor_index;
+    std::vector<dcscn_layer_info> layers;
+    std::vector<WsBuf> bufs;
+    std::vector<Op> ops;
+
+    // workspace
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    int lay_n = 0, lay_h = 0, lay_w = 0;     // shape the current carve was made for
+    // host-path staging
+    float* io_x = nullptr; float* io_x2 = nullptr; float* io_y = nullptr;
+    size_t io_x_cap = 0, io_y_cap = 0;
+    // bicubic resize (resample.hip): Pillow coefficient tables per (in, out) size, and the intermediate image
+    struct ResampleTable { int ksize = 0; int* d_bounds = nullptr; double* d_kk = nullptr; };
+    std::map<std::pair<int, int>, ResampleTable> resample_tables;
+    float* rs_tmp = nullptr; size_t rs_tmp_cap = 0;
+    // self-ensemble (ensemble.hip): flipped copies, their outputs, float64 mean (as 2 floats per double)
+    float* ens_x = nullptr; float* ens_x2 = nullptr; float* ens_y = nullptr; float* ens_out = nullptr;
+    size_t ens_x_cap = 0, ens_x2_cap = 0, ens_y_cap = 0, ens_out_cap = 0;
+    float* rs_in = nullptr; float* rs_out = nullptr; size_t rs_in_cap = 0, rs_out_cap = 0;
+    // colour path (color.hip): uint8 RGB in, float64 planes, float32 Y; capacities in floats
+    float* col_rgb = nullptr; float* col_d = nullptr; float* col_d2 = nullptr; float* col_y32 = nullptr;
+    size_t col_rgb_cap = 0, col_d_cap = 0, col_d2_cap = 0, col_y32_cap = 0;
+    // spatial tiling of images larger than one pass (run_tiled): gathered tile batch
+    float* tile_x = nullptr; float* tile_x2 = nullptr; float* tile_y = nullptr;
+    size_t tile_x_cap = 0, tile_y_cap = 0;
+    std::vector<void*> device_allocs;
+
+    // LR pixels per pass through the layer chain.  Big passes keep >= ~10 rounds of workgroups per
+    // launch on the 256 CUs (a 128-patch pass left a 10-25 % tail); bounded by workspace_budget.
+    int64_t sub_batch_pixels = 4 << 20;
+    int64_t workspace_budget = (int64_t)48 << 30;   // clamped to a share of the free device memory in dcscn_create
+    bool budget_user_set = false;
+    hipEvent_t done_ev = nullptr;            // recorded behind the last forward, on the stream it ran on
+    std::vector<hipEvent_t> host_ev;         // dcscn_forward: one per chunk of the host-buffer pipeline
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+    bool profile = false;
+    bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
+    bool stream_tail = true;                 // the x4 tail of the same nets as one launch (fuse_tail_stream)
+    bool stream_features = true;             // separable narrow nets: CNN1 .. B2 as one row-streamed launch (fuse_feat_stream)
+    bool split16 = true;                     // eligible contractions on the f16 matrix pipe (conv3_h, conv_nin_h); option "split16" 0 = pure f32 kernels
+    size_t redo_off = 0, redo_ints = 0;      // redo flags of the split16 launches inside the arena (byte offset, count)
+    bool dense_features = true;              // per-layer feature buffers + multi-source NIN GEMM instead of one concat tensor (densify_features)
+    int concat_buf = -1;                     // build_graph: the skip-concat buffer, its slices (offset, logical width)
+    std::vector<std::pair<int, int>> concat_slices;
+    uint64_t carve_gen = 0, tables_gen = 0;  // arena carve generation / generation the multi-source tables were filled for
+    bool nin = true;                         // wide 1x1 convs on the LDS-DMA staged GEMM (conv_nin); option "nin_gemm" 0 = conv_igemm
+    bool fold_force = false;                 // "fold_linear_tail" 2: fold even where the composite does more work than the layers
+    bool fold_tail = true;                   // graph rewrite of the linear tail, see fold_linear_tail(); option "fold_linear_tail" 0 = layer by layer
+    bool spatial_tiling = true;              // images larger than one pass are cut into haloed windows (run_tiled)
+    std::vector<hipEvent_t> ev;              // event pool: 2 per launch
+    size_t ev_used = 0;                      // events recorded since the last dcscn_get_profile
+    int ev_forwards = 0;                     // forwards recorded since the last dcscn_get_profile
+    std::vector<double> prof_ms;
+};
+
+namespace dcscn_impl {
+
+extern thread_local std::string g_global_error;
+void set_global_error(const char* fmt, ...);
+int fail(dcscn_ctx* h, int code, const char* fmt, ...);
+
+#define HIP_TRY(h, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, DCSCN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+inline float* buf_ptr(dcscn_ctx* h, int id) { return reinterpret_cast<float*>(static_cast<char*>(h->arena) + h->bufs[id].offset); }
+
+// graph.hip
+void filter_schedule(int layers, int filters, int min_filters, double gamma, std::vector<int>& out);
+int new_buf(dcscn_ctx* h, int stride, int res);
+int kernel_act(int activator, float* const_alpha);
+int build_graph(dcscn_ctx* h);
+int op_tiles16(const Op& op);
+bool nin_eligible(const dcscn_ctx* h, const Op& op);
+bool wino_eligible(const dcscn_ctx* h, const Op& op);
+bool fold_linear_tail(dcscn_ctx* h);
+int stream_chunk_channel(int quads, int ch, int q, int s);
+bool stream_conv_supported(int in_quads, int out_tiles);
+void fuse_feat_stream(dcscn_ctx* h);
+void fuse_tail_stream(dcscn_ctx* h);
+void densify_features(dcscn_ctx* h);
+// pack.hip
+int upload(dcscn_ctx* h, const void* host, size_t bytes, void** dev);
+int finalize_op(dcscn_ctx* h, Op& op);
+int pack_feat_stream(dcscn_ctx* h, Op& op);
+int pack_tail_stream(dcscn_ctx* h, Op& op);
+// exec.hip
+int ensure_workspace(dcscn_ctx* h, int nb, int H, int W, hipStream_t stream);
+int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, const float* x2, float* y, hipStream_t stream);
+int halo_lr_pixels(const dcscn_ctx* h);
+int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, int H, int W, hipStream_t stream);
+int run_tiled(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, int H, int W, int64_t pass_pixels, hipStream_t stream);
+int resample_table(dcscn_ctx* h, int in_size, int out_size, const dcscn_ctx::ResampleTable** out);
+int grow(dcscn_ctx* h, float** p, size_t* cap, size_t floats, hipStream_t stream);
+int resize_device(dcscn_ctx* h, const float* in, float* out, int n, int H, int W, int OH, int OW, hipStream_t stream);
+
+}  // namespace dcscn_impl

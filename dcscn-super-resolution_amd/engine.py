@@ -291,8 +291,11 @@ class Engine:
         self._check(self._lib.dcscn_set_tensor(self._h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                                                shape, a.ndim))
 
-    def load_weights(self, tensors, winograd=None, fold_tail=None):
+    def load_weights(self, tensors, winograd=None, fold_tail=None, split16=None):
         """Feed every variable the graph needs from ``{name: ndarray}`` and finalize.
+        ``split16=False`` (or DCSCN_SPLIT16=0) keeps every contraction on the f32 kernels; the library default runs the wide
+        3x3 and 1x1 convs on the f16 matrix pipe at f32 accuracy (f16 hi/lo split, 3 products, f32 accumulate -- "split16"
+        in include/dcscn.h; the option can also be flipped after finalize with ``set_option("split16", 0 / 1)``).
         ``winograd=False`` keeps every 3x3 conv on the direct implicit-GEMM kernel (default: library choice).
         ``fold_tail=False`` executes the reference's layers one by one; the library default runs the linear tail (last
         pixel-shuffler conv, depth_to_space, last reconstruction conv) as one 5x5 conv where that is less work;
@@ -300,6 +303,10 @@ class Engine:
         such a tail -- see "fold_linear_tail" in include/dcscn.h."""
         if winograd is not None:
             self.set_option("winograd", 1 if winograd else 0)
+        if split16 is None and os.environ.get("DCSCN_SPLIT16") in ("0", "1"):
+            split16 = os.environ["DCSCN_SPLIT16"] == "1"
+        if split16 is not None:
+            self.set_option("split16", 1 if split16 else 0)
         if fold_tail is None and os.environ.get("DCSCN_FOLD_TAIL") in ("0", "1"):
             fold_tail = os.environ["DCSCN_FOLD_TAIL"] == "1"
         if fold_tail is not None:

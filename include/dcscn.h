@@ -169,7 +169,13 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * <= 7 feature layers of <= 32 filters, NIN of <= 32 channels) run CNN1 .. CNNL, A1 || B1 and B2 as ONE row-streamed launch
  * with every intermediate tensor in LDS, and -- x4 models with a 32-channel pixel shuffler -- Up-PS, Up-PS2, the last
  * reconstruction conv and the residual add as a second one.  0 = the layer-by-layer launches (same function, f32 results
- * differ by accumulation order only). */
+ * differ by accumulation order only).
+ * "split16" (default 1; any time): the 3x3 convs the Winograd kernel would take and the wide 1x1 convs run their contraction
+ * on the f16 matrix pipe at f32 accuracy -- every f32 operand as an f16 (hi, lo) pair, three products per MAC, f32
+ * accumulation; measured error below the f32 kernels' (profiles/r03_f16x3_numerics.txt).  An activation beyond the f16 range
+ * (|x| >= 65520) makes the affected outputs non-finite; the kernel flags their 16x16 tile / 256-pixel block and the f32
+ * kernel, launched behind it, recomputes exactly the flagged units -- so the result is f32-exact-safe for any input and does
+ * not depend on what else is in the batch.  0 = the pure f32 kernels (conv_wino2 / conv_nin). */
 int dcscn_set_option(dcscn_handle h, const char* key, int64_t value);
 
 /* Forward pass on host buffers: H2D, kernels, D2H, synchronous. */

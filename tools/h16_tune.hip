@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../dcscn-super-resolution_amd/csrc/conv_nin_h.hpp"
+#include "../dcscn-super-resolution_amd/csrc/conv_nin_h2.hpp"
 #include "../dcscn-super-resolution_amd/csrc/split16_pack.hpp"
 #ifdef H16_CONV3
 #include "../dcscn-super-resolution_amd/csrc/conv3_h.hpp"
@@ -112,6 +113,7 @@ static int padded_col(int cc, int nt, int n_full) {
 // ----------------------------------------------------------------------------------------------------------------------
 // conv_nin vs conv_nin_h
 // ----------------------------------------------------------------------------------------------------------------------
+static int g_S = 2;       // input stages of conv_nin_h (NT = 6 cases): argv "nin 3" / "nin 4"
 struct NinCase { const char* name; long long npix; std::vector<int> widths; int cout; bool multi; };
 
 static int run_nin(const NinCase& C, bool timing, int overflow_test) {
@@ -165,6 +167,11 @@ static int run_nin(const NinCase& C, bool timing, int overflow_test) {
         }
     const int e = split16_scale_exp(dense.data(), dense.size());
     std::vector<uint16_t> p16 = pack_nin16(dense, n_chunks * 16, ctot, ng, nt, n_chunks, e);
+    const int n_chunks32 = (cin_phys + 31) / 32;              // conv_nin_h2: 32-channel chunks, pack_conv16 image with one tap
+    std::vector<uint16_t> p16b = pack_conv16(dense, 1, n_chunks * 16, ctot, ng, nt, n_chunks32, e);
+    void* d_p16b;
+    CK(hipMalloc(&d_p16b, p16b.size() * 2));
+    CK(hipMemcpy(d_p16b, p16b.data(), p16b.size() * 2, hipMemcpyHostToDevice));
     float *d_w, *d_p32, *d_bias, *d_alpha, *d_bp, *d_ap, *d_ref, *d_o32, *d_o16;
     void* d_p16;
     int* d_redo;
@@ -184,13 +191,13 @@ static int run_nin(const NinCase& C, bool timing, int overflow_test) {
     // source table (api.hip: densify_features): one entry per 16-byte quad of the virtual concat
     NinSrcQuad* d_tab = nullptr;
     if (C.multi) {
-        std::vector<NinSrcQuad> tab((size_t)n_chunks * 4, NinSrcQuad{0, 0, 0});
+        std::vector<NinSrcQuad> tab((size_t)n_chunks32 * 8, NinSrcQuad{0, 0, 0});   // >= n_chunks * 4: both kernels read this table
         int q = 0;
         for (int i = 0; i < nsrc; ++i) {
             const int st = (C.widths[i] + 3) & ~3;
             for (int j = 0; j < st / 4; ++j, ++q) tab[q] = NinSrcQuad{(unsigned long long)(uintptr_t)(d_src[i] + 4 * j), (unsigned)(st * 4), 1u};
         }
-        for (; q < n_chunks * 4; ++q) tab[q] = NinSrcQuad{(unsigned long long)(uintptr_t)d_src[0], 0u, 0u};
+        for (; q < n_chunks32 * 8; ++q) tab[q] = NinSrcQuad{(unsigned long long)(uintptr_t)d_src[0], 0u, 0u};
         CK(hipMalloc(&d_tab, tab.size() * sizeof(NinSrcQuad)));
         CK(hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(NinSrcQuad), hipMemcpyHostToDevice));
     }
@@ -226,7 +233,30 @@ static int run_nin(const NinCase& C, bool timing, int overflow_test) {
         b.redo_check = redo_check ? 1 : 0;
         float ms;
         const int reps = timing ? 5 : 1;
-        if (h16) {
+        if (h16 && g_S >= 12) {                // conv_nin_h2 (K = 32 chunks, 128-pixel blocks): "nin 12" = 2 stages, "nin 13" = 3 stages
+            b.wpack16 = d_p16b; b.n_chunks = n_chunks32;
+            const dim3 grid2((unsigned)((npix + 127) / 128), (unsigned)ng);
+            const size_t tab2 = C.multi ? (size_t)n_chunks32 * 128 : 0;
+            if (g_S == 12) {
+                const size_t lds = NinH2Geom<NTc, 2>::LDS_BYTES + tab2;
+                if (C.multi) { auto k = conv_nin_h2<NTc, true, 2>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
+                else { auto k = conv_nin_h2<NTc, false, 2>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
+            } else {
+                const size_t lds = NinH2Geom<NTc, 3>::LDS_BYTES + tab2;
+                if (C.multi) { auto k = conv_nin_h2<NTc, true, 3>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
+                else { auto k = conv_nin_h2<NTc, false, 3>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
+            }
+        } else if (h16 && g_S > 2 && NTc == 6) {      // deeper input prefetch (3 / 4 stages), NT = 6 only
+            if (g_S == 3) {
+                const size_t lds = NinHGeom<6, 3>::LDS_BYTES + tab_bytes;
+                if (C.multi) { auto k = conv_nin_h<6, true, 3>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
+                else { auto k = conv_nin_h<6, false, 3>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
+            } else {
+                const size_t lds = NinHGeom<6, 4>::LDS_BYTES + tab_bytes;
+                if (C.multi) { auto k = conv_nin_h<6, true, 4>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
+                else { auto k = conv_nin_h<6, false, 4>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
+            }
+        } else if (h16) {
             const size_t lds = NinHGeom<NTc>::LDS_BYTES + tab_bytes;
             if (C.multi) { auto k = conv_nin_h<NTc, true>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
             else { auto k = conv_nin_h<NTc, false>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
@@ -289,7 +319,7 @@ static int run_nin(const NinCase& C, bool timing, int overflow_test) {
     for (float* p : d_src) if (p) CK(hipFree(p));
     if (d_one) CK(hipFree(d_one));
     if (d_tab) CK(hipFree(d_tab));
-    CK(hipFree(d_w)); CK(hipFree(d_p32)); CK(hipFree(d_p16)); CK(hipFree(d_bias)); CK(hipFree(d_alpha)); CK(hipFree(d_bp)); CK(hipFree(d_ap));
+    CK(hipFree(d_w)); CK(hipFree(d_p32)); CK(hipFree(d_p16)); CK(hipFree(d_p16b)); CK(hipFree(d_bias)); CK(hipFree(d_alpha)); CK(hipFree(d_bp)); CK(hipFree(d_ap));
     CK(hipFree(d_ref)); CK(hipFree(d_o32)); CK(hipFree(d_o16)); CK(hipFree(d_redo));
     return bad;
 }
@@ -302,6 +332,8 @@ int main(int argc, char** argv) {
     const char* mode = argc > 1 ? argv[1] : "nin";
     int bad = 0;
     if (!strcmp(mode, "nin")) {
+        if (argc > 2) g_S = atoi(argv[2]);
+        printf("conv_nin_h input stages: %d\n", g_S);
         const std::vector<int> l12 = {196, 166, 148, 133, 120, 108, 97, 86, 76, 66, 57, 48};
         const std::vector<int> l8 = {96, 82, 75, 68, 62, 57, 52, 48};
         // edge cases first (full comparison against the float64 reference)
