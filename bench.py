@@ -14,14 +14,20 @@ resident in HBM and y left in HBM.  Weights are seeded synthetic (the trained L1
 The graph executed is the library default (linear tail folded into one 5x5 conv, include/dcscn.h
 "fold_linear_tail"); the layer-by-layer graph is timed beside it at N = 1 (``layer_by_layer``).
 
+Arithmetic: the library default ("split16", include/dcscn.h) runs the 3x3 stack and the wide 1x1 convs on the f16 matrix
+pipe at f32 accuracy -- every f32 operand as an f16 (hi, lo) pair, three products per MAC, f32 accumulation (measured error
+below the f32 kernels', profiles/r03_f16x3_numerics.txt); everything else is f32.  The pure-f32 kernels (split16 = 0) are
+timed in the same line (`f32_path`).  With N > 1 the line also carries the strong-scaling leg of BASELINE configs[2]
+(`strong_scaling`: 1024 patches in total, 1024 / N per rank).
+
 Rank 0 prints one JSON line: LR Mpixels/s over all GPUs, plus
-  roofline      -- the dominant kernel (conv_wino2, the 3x3 convs on f32 MFMA): `achieved` = the FLOPs the
-                   kernel really issues per step / its summed launch time, measured with HIP events on the
-                   launch stream inside the timed steps; `frac` = achieved / f32 MFMA peak = matrix-pipe
-                   utilisation (<= 1).  The direct-form (algorithmic) FLOP rate of the same launches is
-                   reported separately (`algorithmic_tflops`, `algorithmic_speedup_vs_direct_peak`).
-                   `traffic` is REPLAYED from the committed rocprofv3 PMC passes of this command
-                   (profiles/r*_pmc_per_dispatch.json): PMC counters cannot be read in-process.
+  roofline      -- the dominant kernel (the 3x3 convs: conv3_h on v_mfma_f32_16x16x32_f16, or conv_wino2 on f32 MFMA with
+                   split16 = 0): `achieved` = the FLOPs the kernel really issues per step / its summed launch time, measured
+                   with HIP events on the launch stream inside the timed steps; `frac` = achieved / dense MFMA peak of the
+                   instruction's dtype = matrix-pipe utilisation (<= 1); `useful_frac` leaves out channel padding.  The
+                   direct-form (algorithmic, f32-equivalent) FLOP rate of the same launches is reported against the f32 peak
+                   (`vs_f32_peak`).  `traffic` and `sustained_clock_GHz` are REPLAYED from the committed rocprofv3 PMC passes of
+                   this command (profiles/r*_pmc_per_dispatch.json): PMC counters cannot be read in-process.
   cpu_baseline  -- the float32 torch-CPU restatement of the same graph (oracle/cpu_path_torch.py;
                    TensorFlow is not installable) timed on the host cores on a bounded sample.
 """
@@ -42,6 +48,7 @@ PATCHES_PER_GPU = 1024
 MODEL_FLAGS = dict()          # defaults of helper/args.py = dcscn_L12_F196to48_NIN_A64_PS_R1F32, scale 2
 MODEL_NAME = "dcscn_L12_F196to48_NIN_A64_PS"
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (at 2.4 GHz)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -49,6 +56,9 @@ def _pmc_file():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_dispatch.json")))
     return files[-1] if files else None
+
+
+DOM_PREFIX = ["conv3_h"]      # kernel-name prefix of the dominant launches in the PMC file (set from the run: conv3_h / conv_wino)
 
 
 def pmc_replay(dom_ms, nin_ms, algorithmic_bytes):
@@ -66,7 +76,7 @@ def pmc_replay(dom_ms, nin_ms, algorithmic_bytes):
         kernels = doc["kernels"]
         fetch = write = 0.0
         for name, k in kernels.items():
-            if name.startswith("conv_wino") and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+            if name.startswith(DOM_PREFIX[0]) and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
                 per_forward = k["dispatches"] / max(k.get("forwards", 4), 1)
                 fetch += k["FETCH_SIZE"] * 1024.0 * per_forward
                 write += k["WRITE_SIZE"] * 1024.0 * per_forward
@@ -85,16 +95,20 @@ def pmc_replay(dom_ms, nin_ms, algorithmic_bytes):
                                    "note": "counter bytes (corrected) / this run's kernel time; the 3x3 stack is a dense f32 "
                                            "contraction (AI 117-404 FLOP/B): MFMA bound, not HBM bound"}
         for name, k in kernels.items():
-            if (name.startswith("conv_nin<") or name.startswith("conv_igemm<1,")) and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
+            if (name.startswith("conv_nin") or name.startswith("conv_igemm<1,")) and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
                 active = k["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs
+                if DOM_PREFIX[0] == "conv3_h" and not name.startswith("conv_nin_h"):
+                    continue                                  # the f32 fallback launch behind conv_nin_h (empty)
                 ns["nin_1x1"] = {"kernel": name, "mfma_util": round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * active), 4),
+                                 "sustained_clock_GHz": round(active / k["avg_duration_ns_profiled"], 3) if k.get("avg_duration_ns_profiled") else None,
                                  "lds_bank_conflict_frac": round(k["SQ_LDS_BANK_CONFLICT"] / k["SQ_LDS_IDX_ACTIVE"], 4) if k.get("SQ_LDS_IDX_ACTIVE") else None,
                                  "ms_per_step": round(nin_ms, 4),
                                  "note": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x active cycles), fused B1+A1 GEMM"}
-            if name.startswith("conv_wino") and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
+            if name.startswith(DOM_PREFIX[0]) and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
                 active = k["GRBM_GUI_ACTIVE"] / 8.0
-                ns.setdefault("wino_3x3", {})[name] = {
+                ns.setdefault("conv_3x3", {})[name] = {
                     "mfma_util": round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * active), 4),
+                    "sustained_clock_GHz": round(active / k["avg_duration_ns_profiled"], 3) if k.get("avg_duration_ns_profiled") else None,
                     "lds_bank_conflict_frac": round(k["SQ_LDS_BANK_CONFLICT"] / k["SQ_LDS_IDX_ACTIVE"], 4)
                     if k.get("SQ_LDS_IDX_ACTIVE") else None}
         return traffic, ns
@@ -118,6 +132,8 @@ def parse_args():
                     help="skip the extra timing of the layer-by-layer graph")
     ap.add_argument("--layer-by-layer", action="store_true",
                     help="headline on the reference's layers one by one (fold_linear_tail = 0) instead of the library default")
+    ap.add_argument("--no-split16", action="store_true", help="headline on the pure f32 kernels (split16 = 0: conv_wino2 / conv_nin)")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the extra strong-scaling leg (1024 patches in total)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --patches is the GLOBAL batch, split into contiguous shards over the ranks")
     ap.add_argument("--check-output", action="store_true",
@@ -159,7 +175,8 @@ def main():
     cfg = O.make_config(**MODEL_FLAGS)
     weights = O.synthetic_weights(cfg, seed=0)
     eng = engine.Engine(cfg, device=device_index)
-    eng.load_weights(weights, winograd=False if args.no_winograd else None, fold_tail=False if args.layer_by_layer else None)
+    eng.load_weights(weights, winograd=False if args.no_winograd else None, fold_tail=False if args.layer_by_layer else None,
+                     split16=False if (args.no_split16 or args.no_winograd) else None)
     if args.sub_batch_pixels:
         eng.set_option("sub_batch_pixels", args.sub_batch_pixels)
     folded = any("(folded)" in o["name"] for o in eng.ops())
@@ -189,8 +206,22 @@ def main():
     stream = tstream.cuda_stream
     torch.cuda.synchronize()          # inputs were produced on the default stream
 
-    def step():
+    def run_forward():
         eng.forward_device(x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, PATCH, PATCH, stream)
+
+    def step():
+        if share_gpu and world > 1:
+            # Test rig only (several ranks on ONE device): the ranks take turns.  Concurrent dispatch from several PROCESSES to one
+            # MI355X is not a supported deployment of this path -- with conv3_h kernels of another process in flight the results of
+            # a process are no longer bit-reproducible (even its pure f32 kernels: tools/determinism_check.py);
+            # one process per GPU, the real launch, is unaffected.
+            for turn in range(world):
+                if turn == rank:
+                    run_forward()
+                    eng.synchronize()
+                dist.barrier()
+        else:
+            run_forward()
 
     def fence():
         torch.cuda.synchronize()
@@ -226,15 +257,56 @@ def main():
             mine = [d for p in parts for d in p]       # rank order == patch order (contiguous shards)
         digest = hashlib.sha256("".join(mine).encode()).hexdigest()
     global_patches = args.patches if args.strong else n * world
+    # N > 1, weak headline: the strong-scaling leg of BASELINE configs[2] in the same line (one seeded global batch of
+    # PATCHES_PER_GPU patches, contiguous shard per rank), timed exactly like the headline
+    strong_leg = None
+    if world > 1 and not args.strong and not args.no_strong_leg:
+        from dcscn_amd import shard
+        lo, hi = shard.shard_bounds(PATCHES_PER_GPU, rank, world)
+        ns_ = hi - lo
+        gcpu = torch.Generator(device="cpu")
+        gcpu.manual_seed(1234)
+        xg = torch.rand((PATCHES_PER_GPU, PATCH, PATCH, 1), generator=gcpu) * 255.0
+        x2g = torch.rand((PATCHES_PER_GPU, PATCH * s, PATCH * s, 1), generator=gcpu) * 255.0
+        xs_, x2s_ = xg[lo:hi].cuda(), x2g[lo:hi].cuda()
+        del xg, x2g
+        ys_ = torch.empty_like(x2s_)
+        torch.cuda.synchronize()
+
+        def sstep():
+            eng.forward_device(xs_.data_ptr(), x2s_.data_ptr(), ys_.data_ptr(), ns_, PATCH, PATCH, stream)
+        for _ in range(max(args.warmup, 1)):
+            sstep()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            sstep()
+        fence()
+        el_s = time.perf_counter() - t1
+        t = torch.tensor([el_s], device="cpu" if share_gpu else "cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_s = float(t.item())
+        strong_leg = {"value": round(PATCHES_PER_GPU * PATCH * PATCH * args.steps / el_s / 1e6, 4), "unit": "LR Mpix/s",
+                      "ms_per_step": round(el_s / args.steps * 1e3, 4), "scaling": "strong", "global_patches": PATCHES_PER_GPU,
+                      "patches_on_rank0": ns_,
+                      "note": "BASELINE configs[2] as written: 1024 patches in total, contiguous shards of 1024 / N per rank, "
+                              "barrier + max over ranks like the headline"}
 
     if rank == 0:
         ops = eng.ops()
         lr_pixels = n * PATCH * PATCH                         # this rank's
         global_lr_pixels = global_patches * PATCH * PATCH
         # dominant kernel: the Winograd 3x3 launches (CNN2..12, B2, and Up-PS in the layer-by-layer graph)
-        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino2")
+        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino2", "conv3_h")
                and o["kernel_size"] == 3 and o["out_channels"] > 1]
         dom_kernels = sorted({o["kernel"] for o, _ in dom})
+        on_f16 = "conv3_h" in dom_kernels
+        DOM_PREFIX[0] = "conv3_h" if on_f16 else "conv_wino"
+        dom_peak = PEAK_F16_MFMA_TFLOPS if on_f16 else PEAK_F32_MFMA_TFLOPS
+        # FLOPs the instruction stream would issue without channel padding: 3 f16 products per MAC (conv3_h), or the 16/36
+        # of F(2x2,3x3) (conv_wino2)
+        dom_useful = dom_flop_useful = sum(2.0 * o["macs_per_lr_pixel"] * (3.0 if o["kernel"] == "conv3_h" else 16.0 / 36.0 if o["kernel"] == "conv_wino2" else 1.0)
+                                            for o, _ in dom) * lr_pixels
         dom_flop = sum(2.0 * o["macs_per_lr_pixel"] for o, _ in dom) * lr_pixels
         dom_bytes = sum(float(o["bytes_per_lr_pixel"]) for o, _ in dom) * lr_pixels
         dom_ms = sum(ms for _, ms in dom)
@@ -245,7 +317,7 @@ def main():
         kernel_ms = sum(per_op_ms)
         per_kernel = {}
         for o, ms in zip(ops, per_op_ms):
-            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] in ("conv_igemm", "conv_wino2") else "")
+            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] in ("conv_igemm", "conv_wino2", "conv3_h") else "")
             per_kernel[key] = per_kernel.get(key, 0.0) + ms
         if args.ops:
             for o, ms in zip(ops, per_op_ms):
@@ -256,7 +328,7 @@ def main():
                       % (o["name"], o["kernel"], o["kernel_size"], o["in_channels"], o["out_channels"], o["resolution"],
                          o["mt"], o["nt"], o["kc"], o["n_tiles"], ms, fl / (ms * 1e-3) / 1e12 if ms else 0,
                          fx / (ms * 1e-3) / 1e12 if ms else 0, by / (ms * 1e-3) / 1e9 if ms else 0), file=sys.stderr)
-        nin_ms = sum(ms for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_nin") and o["kernel_size"] == 1)
+        nin_ms = sum(ms for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_nin", "conv_nin_h") and o["kernel_size"] == 1)
         full_workload = n == PATCHES_PER_GPU and not args.no_winograd
         traffic, north_star = pmc_replay(dom_ms, nin_ms, dom_bytes) if full_workload else (None, None)
         graph = ("linear tail (Up-PS conv + depth_to_space + R-CNN1) folded into one 5x5 conv -- library default, include/dcscn.h fold_linear_tail"
@@ -272,7 +344,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("f32-equivalent (3x3 stack and wide 1x1 convs: f16 hi/lo split, 3 products per MAC, f32 accumulate -- error below the "
+                      "f32 kernels'; everything else f32)") if on_f16 else "f32",
             "data": "synthetic (uniform 0-255 Y patches, seeded He-init weights; trained L12 blobs are not shipped)",
             "config": {
                 "workload": "%s x2 forward, %s (BASELINE.json configs[2])" % (
@@ -281,30 +354,41 @@ def main():
                 "patches_per_gpu": n,
                 "global_patches": global_patches,
                 "parallelism": "image-shard x%d, no collective" % world,
-                "flop_per_lr_pixel": 2 * total_macs,
+                "flop_per_lr_pixel_direct_form": 2 * total_macs,
                 "graph": graph,
+                "arithmetic": "split16 (include/dcscn.h)" if on_f16 else "f32 kernels (split16 = 0)",
             },
             "roofline": {
-                "kernel": "%s 3x3 (v_mfma_f32_16x16x4_f32), %d launches/pass" % ("+".join(dom_kernels), len(dom)),
+                "kernel": "%s 3x3 (%s), %d launches/pass" % ("+".join(dom_kernels), "v_mfma_f32_16x16x32_f16, f16 hi/lo x 3 products" if on_f16
+                                                             else "v_mfma_f32_16x16x4_f32", len(dom)),
                 "bound": "mfma",
                 "achieved": round(executed, 3),
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": dom_peak,
                 "unit": "TFLOP/s",
-                "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+                "frac": round(executed / dom_peak, 4),
+                "useful_frac": round(dom_useful / (dom_ms * 1e-3) / 1e12 / dom_peak, 4) if dom_ms > 0 else None,
                 "traffic": traffic["bytes_per_step"] if traffic else None,
                 "traffic_detail": traffic,
                 "executed_flop_per_step": dom_exec,
                 "algorithmic_flop_per_step": dom_flop,
-                "algorithmic_tflops": round(algorithmic, 3),
-                "algorithmic_speedup_vs_direct_peak": round(algorithmic / PEAK_F32_MFMA_TFLOPS, 4),
-                "note": "achieved = FLOPs the kernel issues (Winograd F(2x2,3x3): 16/36 of the direct form, plus channel padding "
-                        "to 16 / 8) per second of its own launch time (HIP events on the launch stream); frac = matrix-pipe "
-                        "utilisation.  algorithmic_* count the direct-form FLOPs of SURVEY.md 8(d) for the same launches.",
+                "vs_f32_peak": {"algorithmic_tflops": round(algorithmic, 3), "peak": PEAK_F32_MFMA_TFLOPS,
+                                "ratio": round(algorithmic / PEAK_F32_MFMA_TFLOPS, 4),
+                                "note": "direct-form f32 FLOPs of SURVEY.md 8(d) for the same launches per second, against the f32 "
+                                        "MFMA / VALU peak the reference's arithmetic is bound by"},
+                "note": ("achieved = f16 FLOPs the kernel issues (3 products per MAC, input channels padded to 32, output channels to 16) "
+                         "per second of its own launch time (HIP events on the launch stream); frac = matrix-pipe utilisation against the "
+                         "dense f16 peak at the nominal 2.4 GHz -- the chip sustains ~1.8 GHz under this kernel (replayed PMC: "
+                         "north_star.conv_3x3.*.sustained_clock_GHz), i.e. ~0.75 of that peak is the power-limited ceiling; useful_frac "
+                         "leaves out the padding." if on_f16 else
+                         "achieved = FLOPs the kernel issues (Winograd F(2x2,3x3): 16/36 of the direct form, plus channel padding to 16 / 8) "
+                         "per second of its own launch time (HIP events on the launch stream); frac = matrix-pipe utilisation."),
                 "kernel_ms_per_step": round(dom_ms, 4),
             },
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_kernel.items())},
-            "whole_net_tflops": round(2.0 * total_macs * lr_pixels / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms else None,
+            "whole_net_tflops_direct_form_equivalent": round(2.0 * total_macs * lr_pixels / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms else None,
         }
+        if strong_leg is not None:
+            result["strong_scaling"] = strong_leg
         if digest is not None:
             result["output_sha256"] = digest
         if north_star:
@@ -352,6 +436,30 @@ def main():
                 }
             except Exception as exc:
                 result["host_path"] = {"error": str(exc)}
+        if world == 1 and on_f16 and not args.no_extra_graph:
+            # beside the headline: the same engine on the pure f32 kernels (split16 = 0), same inputs, timed the same way
+            try:
+                y_h16 = y.clone()
+                eng.set_option("split16", 0)
+                for _ in range(max(args.warmup, 1)):
+                    step()
+                eng.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                eng.synchronize()
+                el3 = time.perf_counter() - t1
+                result["f32_path"] = {
+                    "value": round(lr_pixels * args.steps / el3 / 1e6, 4), "unit": "LR Mpix/s",
+                    "ms_per_step": round(el3 / args.steps * 1e3, 4),
+                    "max_abs_diff_vs_split16": float((y - y_h16).abs().max().item()),
+                    "note": "split16 = 0: 3x3 convs on conv_wino2 (f32 Winograd on v_mfma_f32_16x16x4_f32), 1x1 on conv_nin -- the r02 headline path",
+                }
+                eng.set_option("split16", 1)
+                step()
+                eng.synchronize()
+            except Exception as exc:
+                result["f32_path"] = {"error": str(exc)}
         if world == 1 and folded and not args.no_extra_graph:
             # beside the headline: the same inputs through the layer-by-layer graph (fold_linear_tail = 0), timed the same way
             try:

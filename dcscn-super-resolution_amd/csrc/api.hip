@@ -197,7 +197,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     const Op& op = h->ops[index];
     memset(out, 0, sizeof *out);
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
-    const bool s16 = h->split16 && op.h16.on;
+    const bool s16 = h->split16 && op.h16.on && (h->split16_mask & (op.shape.nin ? 2 : 1));
     snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (s16 ? (op.shape.nin ? "conv_nin_h" : "conv3_h") : op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
@@ -281,6 +281,7 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     }
     if (!strcmp(key, "split16")) {                  // any time: the f16 images are always built, the option picks the launch
         h->split16 = value != 0;
+        h->split16_mask = value == 2 ? 1 : value == 3 ? 2 : 3;
         return DCSCN_OK;
     }
     if (!strcmp(key, "profile")) {

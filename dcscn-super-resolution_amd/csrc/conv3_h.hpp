@@ -20,7 +20,7 @@
 //   outside the image and channels past cin are written as zeros: that is the SAME padding.
 // * filters: f16 (hi, lo) A fragments packed by the host (split16_pack.hpp: pack_conv16) in read order, one tap = NT * 2 KB,
 //   a ring of three tap slots in LDS filled by LDS-DMA (conv_wino2.hpp: glds16) two taps ahead; the wait before a tap's barrier
-//   is a COUNTED vmcnt that leaves the next tap's pieces (and, early in a chunk, the input loads) in flight.
+//   is a COUNTED vmcnt that leaves the next tap's pieces in flight.
 //   One barrier per tap, two more per chunk around the write of the input image.  LDS = 41.5 + NT * 6 KB: two workgroups per CU.
 // * the chunk's input values are converted to (hi, lo) in registers a few per tap while the chunk's later taps compute (the
 //   f16 MFMA leaves two VALU issue slots per instruction free, profiles/r03_pipe_probe.txt); only the LDS writes sit between
@@ -172,31 +172,26 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
     load_in(0);
     static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL { convert_in(r_, 0); });
     store_in();
-    // K loop.  Per tap: wait for this tap's filter pieces (counted: the next tap's stay in flight), barrier, refill the slot the
-    // previous tap was read from with the tap after next, compute.  vmcnt retires in order, so a filter wait also waits for every
-    // older operation: the chunk's 11 input loads are issued at tap 0 BEHIND that tap's DMA and are first forced by the wait of
-    // tap 3 (three taps = ~2.5 k cycles after issue); the waits of taps 1 and 2 count them as in flight.
+    // K loop.  Per tap: wait for this tap's filter pieces, barrier, refill the slot the previous tap was read from with the tap
+    // after next, compute.  The wait is vmcnt(F_ROUNDS): everything but the youngest F_ROUNDS operations has retired.  The
+    // LDS-DMA pieces of a wave retire in issue order, so if a piece of this tap were still in flight all F_ROUNDS pieces of the
+    // next tap would be too -- more than the count allows; the argument needs no ordering between the DMA pieces and the plain
+    // loads of the input values (issued at tap 0 behind that tap's DMA, so the wait of tap 1 retires them: one tap of latency
+    // is hidden, the rest is covered by the other workgroup of the CU).
+    // The loads, the conversion and the DMA are unconditional (the last chunk re-reads itself, the last taps re-fetch the last
+    // tap): no value in the loop depends on a branch, so the compiler keeps ONE register set for the staged values.
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const bool more = chunk + 1 < n_chunks;                // block uniform
+        const int nchunk = more ? chunk + 1 : chunk;
         static_for<0, 9>([&](auto t_) DCSCN_INL {
             constexpr int tap = decltype(t_)::value;
             constexpr int ky = tap / 3, kx = tap % 3;
             constexpr int slot = tap % 3;                      // (chunk * 9 + tap) % 3
             const int g = chunk * 9 + tap;
-            if constexpr (ABL != 3 && ABL != 6) {
-                if constexpr (tap == 1 || tap == 2) {
-                    if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS + G::IN_ROUNDS) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS) : "memory");
-                }
-            }
+            if constexpr (ABL != 3 && ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS) : "memory");
             if constexpr ((ABL != 4 && ABL != 6) || tap == 0) __syncthreads();
-            if constexpr (ABL != 3 && ABL != 6) {
-                // always the same number of operations per wave (the counts above rely on it): past the last tap the last one is re-fetched
-                dma_f(g + 2 < n_taps ? g + 2 : n_taps - 1, (tap + 2) % 3);
-            }
-            if constexpr (tap == 0 && ABL != 2 && ABL != 6) { if (more) load_in(chunk + 1); }
+            if constexpr (ABL != 3 && ABL != 6) dma_f(g + 2 < n_taps ? g + 2 : n_taps - 1, (tap + 2) % 3);
+            if constexpr (tap == 0 && ABL != 2 && ABL != 6) load_in(nchunk);
             h8 xh[4], xl[4];
             static_for<0, 4>([&](auto m_) DCSCN_INL {
                 constexpr int m = decltype(m_)::value;
@@ -217,12 +212,9 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[m], acc[m][n], 0, 0, 0);
                 });
             });
-            // the next chunk's input values become (hi, lo) pairs two items per tap from tap 3 on (their loads are 3+ taps old)
-            if constexpr (tap >= 3 && ABL != 1 && ABL != 2 && ABL != 6) {
-                if (more) {
-                    static_for<2 * (tap - 3), (2 * (tap - 3) + 2 < G::IN_ROUNDS ? 2 * (tap - 3) + 2 : G::IN_ROUNDS)>([&](auto r_) DCSCN_INL { convert_in(r_, chunk + 1); });
-                }
-            }
+            // the next chunk's input values become (hi, lo) pairs two items per tap from tap 3 on
+            if constexpr (tap >= 3 && ABL != 1 && ABL != 2 && ABL != 6)
+                static_for<2 * (tap - 3), (2 * (tap - 3) + 2 < G::IN_ROUNDS ? 2 * (tap - 3) + 2 : G::IN_ROUNDS)>([&](auto r_) DCSCN_INL { convert_in(r_, nchunk); });
         });
         if constexpr (ABL != 1 && ABL != 2 && ABL != 6) {
             if (more) {

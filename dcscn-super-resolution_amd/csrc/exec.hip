@@ -106,13 +106,16 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.n_jobs = (int)(cols * a.n_blocks);
         a.jobs_per_wg = (a.n_jobs + 255) / 256;
         const int grid = (a.n_jobs + a.jobs_per_wg - 1) / a.jobs_per_wg;
+#ifdef STREAM_DBG                              // timing-probe builds only (tools/stream_dbg.sh): shader clocks of workgroup 0 to a file
         static long long* dbg = nullptr;
         if (getenv("DCSCN_STREAM_DBG")) {
             if (!dbg) HIP_TRY(h, hipMalloc((void**)&dbg, 16 * 64 * 4 * sizeof(long long)));
             HIP_TRY(h, hipMemsetAsync(dbg, 0, 16 * 64 * 4 * sizeof(long long), stream));
             a.dbg = dbg;
         }
+#endif
         HIP_TRY(h, stream_launch(a, grid, stream));
+#ifdef STREAM_DBG
         if (a.dbg) {
             std::vector<long long> host(16 * 64 * 4);
             HIP_TRY(h, hipStreamSynchronize(stream));
@@ -125,6 +128,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
                 fclose(f);
             }
         }
+#endif
         return DCSCN_OK;
     }
     if (op.kind == OP_DW) {
@@ -207,7 +211,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     a.dwk = op.dwk;
     a.fold = op.fold_s > 0 ? 1 : 0;
     a.srctab = op.multi.empty() ? nullptr : op.d_srctab;
-    if (h->split16 && op.h16.on) {
+    if (h->split16 && op.h16.on && (h->split16_mask & (op.shape.nin ? 2 : 1))) {
         // the contraction on the f16 matrix pipe; units with a non-finite output (an activation beyond the f16 range) raise their
         // redo flag and the f32 launch below recomputes exactly those (it exits at once everywhere else)
         ConvArgs b = a;

@@ -166,6 +166,7 @@ struct dcscn_ctx {
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
     bool stream_tail = true;                 // the x4 tail of the same nets as one launch (fuse_tail_stream)
     bool stream_features = true;             // separable narrow nets: CNN1 .. B2 as one row-streamed launch (fuse_feat_stream)
+    int split16_mask = 3;                    // debugging aid (option "split16" 2 / 3): bit 0 = conv3_h, bit 1 = conv_nin_h
     bool split16 = true;                     // eligible contractions on the f16 matrix pipe (conv3_h, conv_nin_h); option "split16" 0 = pure f32 kernels
     size_t redo_off = 0, redo_ints = 0;      // redo flags of the split16 launches inside the arena (byte offset, count)
     bool dense_features = true;              // per-layer feature buffers + multi-source NIN GEMM instead of one concat tensor (densify_features)

@@ -46,8 +46,10 @@ def _parse_tensor(buf):
         return np.frombuffer(content, dtype="<f4").reshape(shape).astype(np.float32)
     if len(floats) == count:
         return np.asarray(floats, np.float32).reshape(shape)
-    if len(floats) == 1:                                   # one value broadcast over the shape (how TF stores constant fills)
-        return np.full(shape, floats[0], np.float32)
+    if 0 < len(floats) < count:
+        # TensorFlow stores a tensor whose tail repeats one value with that tail truncated (one float_val = a constant fill):
+        # the missing entries equal the last one given
+        return np.concatenate([np.asarray(floats, np.float32), np.full(count - len(floats), floats[-1], np.float32)]).reshape(shape)
     if not floats and count:
         return np.zeros(shape, np.float32)
     raise CheckpointError("Const tensor: %d float_val entries for shape %s" % (len(floats), shape))

@@ -74,6 +74,8 @@ class SuperResolution:
         self.pixel_shuffler = flags.pixel_shuffler
         self.pixel_shuffler_filters = flags.pixel_shuffler_filters
         self.self_ensemble = flags.self_ensemble
+        self.ensemble_group = None          # evaluate.py: a shard.Group when the ensemble transforms of an image are spread over ranks
+        self.ensemble_serialize = False     # single-device test rig: ranks take turns on the GPU
         self.depthwise_separable = flags.depthwise_separable
 
         # image processing parameters (DCSCN.py:76-82)
@@ -316,7 +318,12 @@ class SuperResolution:
         eng = self._ready_engine()
         x = np.ascontiguousarray(input_image, dtype=np.float32).reshape(h, w)
         x2 = np.ascontiguousarray(bicubic_input_image, dtype=np.float32).reshape(self.scale * h, self.scale * w)
-        if self.self_ensemble > 1:
+        if self.self_ensemble > 1 and self.ensemble_group is not None:
+            # (image, transform) work items sharded over the ranks (evaluate.py); float64 mean in the reference's order
+            output = self.ensemble_group.ensemble_mean(
+                x[:, :, None], x2[:, :, None], self.self_ensemble,
+                lambda a, b: eng.forward(a[None], b[None])[0], util.flip, serialize=self.ensemble_serialize)
+        elif self.self_ensemble > 1:
             output = eng.forward_ensemble(x, x2, self.self_ensemble)            # float64, like np.zeros + +=
         else:
             output = eng.forward(x[None, :, :, None], x2[None, :, :, None])[0]   # float32, like sess.run
@@ -363,7 +370,8 @@ class SuperResolution:
         """uint8 RGB through the device colour / bicubic kernels: they reproduce the float64 numpy colour math and
         Pillow's mode-'F' BICUBIC only (other resampling methods, other value ranges stay on the host path)."""
         return (self.resampling_method == BICUBIC_METHOD_STRING and self.max_value == 255.0 and self.channels == 1
-                and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3)
+                and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3
+                and self.ensemble_group is None)              # the all-device pipeline runs the whole ensemble on this rank
 
     def _evaluation_inputs(self, file_path):
         """(true image aligned, true Y or grey, LR input, bicubic of LR) -- DCSCN.py:674-683."""

@@ -18,6 +18,27 @@ def shard_bounds(n_items, rank, world):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def assign_longest_first(costs, world):
+    """Greedy longest-processing-time assignment of items with the given costs to ``world`` ranks: items are taken in
+    order of decreasing cost (ties: lower index first) and each goes to the currently least-loaded rank (ties: lower
+    rank).  Returns ``[sorted item indices of rank 0, of rank 1, ...]`` -- deterministic, the same on every rank."""
+    if world <= 0:
+        raise ValueError("bad world %d" % world)
+    load = [0] * world
+    mine = [[] for _ in range(world)]
+    for i in sorted(range(len(costs)), key=lambda k: (-costs[k], k)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += costs[i]
+        mine[r].append(i)
+    return [sorted(m) for m in mine]
+
+
+def split_ensemble(n_items, world, self_ensemble):
+    """with fewer images than 2 x ranks and a self-ensemble, the work items are (image, transform) pairs
+    -- every rank takes transforms t = rank, rank + world, ... of EVERY image -- instead of whole images."""
+    return world > 1 and self_ensemble > 1 and n_items < 2 * world
+
+
 class Group:
     """The process group of this launch (a single process when not launched by torch.distributed.run)."""
 
@@ -40,6 +61,35 @@ class Group:
         if self.world > 1:
             self._dist.barrier()
 
+    def by_turns(self, fn):
+        """Run fn() on one rank at a time (rank 0 first).  Only for the single-device test rig (DCSCN_SHARE_GPU=1): several
+        processes dispatching to ONE MI355X concurrently is not a supported deployment of this path."""
+        out = None
+        for turn in range(self.world):
+            if turn == self.rank:
+                out = fn()
+            self.barrier()
+        return out
+
+    def ensemble_mean(self, image, bicubic, n, forward_one, flip, serialize=False):
+        """Distributed self-ensemble of ONE image (DCSCN.py:559-573): transform t runs on rank t % world, the float32 results
+        are gathered and every rank forms the float64 mean in the reference's order t = 0 .. n-1 (np.zeros float64, +=, / n).
+        ``forward_one(x[h, w, 1], x2[sh, sw, 1]) -> [sh, sw, 1] float32``; ``flip(image, t, invert)`` = util.flip."""
+        import numpy as np
+
+        def mine():
+            parts = []
+            for t in range(self.rank, n, self.world):
+                y = forward_one(np.ascontiguousarray(flip(image, t)), np.ascontiguousarray(flip(bicubic, t)))
+                parts.append((t, np.ascontiguousarray(flip(np.asarray(y, np.float32), t, invert=True))))
+            return parts
+        parts = self.by_turns(mine) if (serialize and self.world > 1) else mine()
+        every = dict(self.gather(parts))
+        out = np.zeros(every[0].shape, dtype=np.float64)
+        for t in range(n):
+            out += every[t]
+        return out / n
+
     def close(self):
         if self.world > 1 and self._dist.is_initialized():
             self._dist.barrier()
@@ -57,9 +107,12 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # DCSCN_SHARE_GPU=1 (test rig: all ranks on device 0) cannot use RCCL: one communicator rank per device
+        backend = "nccl" if torch.cuda.is_available() and os.environ.get("DCSCN_SHARE_GPU") != "1" else "gloo"
     if not dist.is_initialized():
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+        if os.environ.get("DCSCN_SHARE_GPU") == "1":
+            local_rank = 0
         dist.init_process_group(backend, rank=rank, world_size=world)
     return Group(rank, world, local_rank, dist)

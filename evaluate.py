@@ -6,11 +6,20 @@ Builds LR inputs from data/<test_dataset>/, super-resolves them on the MI355X an
 ``Model Average [<set>] PSNR:..., SSIM:..., Time (s): ...`` (evaluate.py:106-107).
 
 One process drives one GPU (``--gpu_device_id``).  Launched under ``torch.distributed.run`` with N
-ranks, the image list is sharded across ranks (contiguous shards, no data-path collective); per-file
-results are gathered on rank 0, which logs the averages.
+ranks the work is partitioned as SURVEY.md 8(e) describes (the reference loops over files and, per file,
+over the self-ensemble transforms: evaluate.py:89-107, DCSCN.py:559-573):
+
+* at least 2 N images: whole images, assigned longest first by pixel count to the least-loaded rank;
+* fewer (Set5 on 8 GPUs) and ``--self_ensemble`` > 1: (image, transform) work items -- every rank runs
+  transforms t = rank, rank + N, ... of every image, the float32 results are gathered and the float64 mean is
+  formed in the reference's order.
+
+Nothing is exchanged on the data path of a forward pass; per-file results are gathered on rank 0, which logs
+the averages.  The PSNR / SSIM values do not depend on N (tests/test_shard.py, tests/test_multi_rank_gpu.py).
 """
 
 import logging
+import os
 import time
 
 import DCSCN
@@ -65,22 +74,47 @@ def evaluate_bicubic(model, test_data, group):
             test_data, sum(r[0] for r in results) / len(results), sum(r[1] for r in results) / len(results)))
 
 
+def _pixel_counts(filenames):
+    from PIL import Image
+    sizes = []
+    for f in filenames:
+        with Image.open(f) as im:
+            sizes.append(im.size[0] * im.size[1])
+    return sizes
+
+
+def _evaluate_file(model, filename, save):
+    start = time.time()
+    if save:
+        psnr, ssim = model.do_for_evaluate_with_output(filename, output_directory=FLAGS.output_dir, print_console=False)
+    else:
+        psnr, ssim = model.do_for_evaluate(filename, print_console=False)
+    return psnr, ssim, time.time() - start
+
+
 def evaluate_model(model, test_data, group):
     test_filenames = util.get_files_in_directory(FLAGS.data_dir + "/" + test_data)
-    mine = []
-    for filename in group.my_items(test_filenames):
-        start = time.time()
-        if FLAGS.save_results:
-            psnr, ssim = model.do_for_evaluate_with_output(filename, output_directory=FLAGS.output_dir,
-                                                           print_console=False)
-        else:
-            psnr, ssim = model.do_for_evaluate(filename, print_console=False)
-        mine.append((psnr, ssim, time.time() - start))
-    results = group.gather(mine)
+    share = os.environ.get("DCSCN_SHARE_GPU") == "1"          # single-device test rig: the ranks take turns on the GPU
+    if shard.split_ensemble(len(test_filenames), group.world, model.self_ensemble):
+        # every rank walks every file; inside model.do the transforms of the image are spread over the ranks
+        model.ensemble_group, model.ensemble_serialize = group, share
+        results = [_evaluate_file(model, f, FLAGS.save_results and group.rank == 0) for f in test_filenames]
+        model.ensemble_group = None
+    else:
+        mine = shard.assign_longest_first(_pixel_counts(test_filenames), group.world)[group.rank]
+
+        def run():
+            return [(i,) + _evaluate_file(model, test_filenames[i], FLAGS.save_results) for i in mine]
+        tagged = group.gather(group.by_turns(run) if share and group.world > 1 else run())
+        results = [r[1:] for r in sorted(tagged)]             # back to file order
     if group.rank == 0:
         n = len(results)
         logging.info("Model Average [%s] PSNR:%f, SSIM:%f, Time (s): %f" % (
             test_data, sum(r[0] for r in results) / n, sum(r[1] for r in results) / n, sum(r[2] for r in results) / n))
+        if os.environ.get("DCSCN_EVAL_DUMP"):               # tests: the per-file values with full precision
+            with open(os.environ["DCSCN_EVAL_DUMP"], "a") as f:
+                for name, r in zip(test_filenames, results):
+                    f.write("%s %s %r %r\n" % (test_data, os.path.basename(name), float(r[0]), float(r[1])))
 
 
 if __name__ == "__main__":

@@ -127,3 +127,36 @@ def test_save_model_and_frozen_inference_reproduce_the_checkpoint_psnr(tmp_path)
     assert p.returncode == 0, p.stdout
     mm = re.search(r"Model Average \[set5\] PSNR:([0-9.]+)", p.stdout)
     assert mm and abs(float(mm.group(1)) - g["models"]["L2_x2"]["set5_mean"]) <= 1e-3, p.stdout
+
+
+def test_frozen_reader_on_a_graph_shaped_like_the_reference_freeze_tool_output():
+    """tests/golden/frozen_L2_ref*.pb (make_ref_frozen.py): the inference sub-graph of the reference's own MetaGraphDef for its
+    shipped L2 checkpoint with every VariableV2 turned into a Const of the same name -- what helper/custom_freeze_graph.py:14-61
+    writes -- and the same with the ``prefix/`` names DCSCN.py:192-220 (load_graph) resolves.  The reader must return exactly
+    the checkpoint's tensors from both."""
+    from dcscn_amd import ckpt, frozen
+    ref = ckpt.load_checkpoint(REF_CKPT)
+    for fname, prefix in (("frozen_L2_ref.pb", ""), ("frozen_L2_ref_prefixed.pb", "prefix/")):
+        path = os.path.join(GOLDEN, fname)
+        nodes = frozen.read_graph_nodes(path)
+        names = {n[0]: n[1] for n in nodes}
+        assert names[prefix + "x"] == names[prefix + "x2"] == "Placeholder" and names[prefix + "output"] in ("Add", "AddV2")
+        assert names[prefix + "CNN1/conv_W"] == "Const" and names[prefix + "CNN1/conv_W/read"] == "Identity"
+        assert not any(op in ("VariableV2", "Variable") for op in names.values())
+        got = frozen.read_frozen_graph(path, prefix=prefix)
+        for k, v in ref.items():
+            assert k in got and got[k].shape == v.shape and np.array_equal(got[k], v), k
+
+
+def test_frozen_reader_pads_a_truncated_float_val_with_its_last_value(tmp_path):
+    """TensorFlow drops the repeated tail of a tensor stored as float_val: 1 < len(float_val) < size is legal."""
+    from dcscn_amd import frozen
+    from dcscn_amd.frozen import _ld, _attr, _shape_proto
+    import struct
+    vals = [1.0, 2.0, 3.0]
+    tensor = b"\x08\x01" + _ld(2, _shape_proto((2, 4))) + _ld(5, struct.pack("<3f", *vals))
+    node = _ld(1, _ld(1, b"CNN1/conv_B") + _ld(2, b"Const") + _attr("dtype", b"\x30\x01") + _attr("value", _ld(8, tensor)))
+    pb = tmp_path / "t.pb"
+    pb.write_bytes(node)
+    t = frozen.read_frozen_graph(str(pb))
+    assert np.array_equal(t["CNN1/conv_B"], np.array([[1, 2, 3, 3], [3, 3, 3, 3]], np.float32))

@@ -74,6 +74,69 @@ def test_residual_branch_relative_error(oracle, name, winograd, fold):
     assert rel <= 5e-6
 
 
+def test_baseline_config3_as_written(oracle):
+    """BASELINE.json configs[3]: dcscn_L12_F196to48 x4 WITH self_ensemble = 8 on an image-sized input (the 8 flips / rotations
+    of DCSCN.py:559-573, four of them transposed, float64 mean) against oracle.do, with split16 on (library default) and off."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS["L12_F196to48_x4"])
+    weights = oracle.synthetic_weights(cfg, seed=3)
+    x, x2 = synthetic_batch(1, 48, 64, 4, seed=21)
+    ref = oracle.do(cfg, weights, x[0], x2[0], self_ensemble=8)
+    for s16 in (True, False):
+        with engine.Engine(cfg, device=0) as eng:
+            eng.load_weights(weights, split16=s16)
+            y = eng.forward_ensemble(x[0], x2[0], 8)
+        err = float(np.max(np.abs(y - ref)))
+        print("L12 x4 self_ensemble=8 on 48x64 split16=%s: max-abs %.3g (max|y| %.1f)" % (s16, err, np.abs(ref).max()))
+        assert y.shape == ref.shape and np.isfinite(y).all() and err <= MAX_ABS_TOL
+
+
+@pytest.mark.parametrize("split16", [True, False])
+@pytest.mark.parametrize("name", ["L8_F96to48_x2", "L12_F196to48_x2", "L7_F32to8_x2"])
+def test_split16_option_both_ways(oracle, name, split16):
+    """The f16-pipe kernels (library default) and the pure f32 kernels behind the same handle: both meet the bars, the
+    option flips the launches (dcscn_op_info) and can be changed after finalize."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS[name])
+    weights = oracle.synthetic_weights(cfg, seed=5)
+    x, x2 = synthetic_batch(2, 40, 56, cfg["scale"], seed=6)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with engine.Engine(cfg, device=0) as eng:
+        eng.load_weights(weights)
+        eng.set_option("split16", 1 if split16 else 0)
+        kernels = {o["kernel"] for o in eng.ops()}
+        assert ("conv3_h" in kernels) == split16 and ("conv_wino2" in kernels) == (not split16), kernels
+        y = eng.forward(x, x2)
+        eng.set_option("split16", 0 if split16 else 1)      # and back the other way on the same handle
+        y2 = eng.forward(x, x2)
+    for out in (y, y2):
+        assert float(np.max(np.abs(out - ref))) <= MAX_ABS_TOL
+
+
+def test_split16_overflow_falls_back_to_f32(oracle):
+    """An activation beyond the f16 range (|x| >= 65520) cannot be split; the kernels flag the affected 16x16 tiles / 256-pixel
+    blocks and the f32 launch behind them recomputes exactly those.  Here the input is scaled so that CNN1's outputs reach
+    ~1e6: the result must still match the float64 oracle to f32 accuracy, and an ordinary image in the same batch must come
+    out bit-identical to a run without the huge one."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS["L8_F96to48_x2"])
+    weights = oracle.synthetic_weights(cfg, seed=9)
+    x, x2 = synthetic_batch(2, 32, 48, 2, seed=10)
+    xb = x.copy()
+    xb[1] *= 4000.0                                            # image 1: activations far beyond 65504
+    ref = oracle.forward(cfg, weights, xb, x2, dtype=np.float64)
+    with engine.Engine(cfg, device=0) as eng:
+        eng.load_weights(weights)
+        y = eng.forward(xb, x2)
+        y0 = eng.forward(x[:1], x2[:1])
+    assert np.isfinite(y).all()
+    rel = float(np.max(np.abs(y[1] - ref[1])) / np.max(np.abs(ref[1])))
+    print("overflowing image: relative error %.3g (max|y| %.3g)" % (rel, np.max(np.abs(ref[1]))))
+    assert rel <= 5e-6
+    assert float(np.max(np.abs(y[0] - ref[0]))) <= MAX_ABS_TOL
+    assert np.array_equal(y[0], y0[0])
+
+
 @pytest.mark.parametrize("hw", [(1, 1), (5, 7), (16, 16), (17, 33), (31, 9), (50, 20)])
 def test_ragged_sizes(oracle, hw):
     """Image sizes that are not multiples of the pixel tiles (odd sizes also cut Winograd's 2x2 output
@@ -447,6 +510,13 @@ def test_streamed_separable_net_matches_layer_by_layer(oracle, shape):
     err = np.abs(outs[1] - outs[0]).max() / scale
     print("streamed vs layered, %s: max rel %.3g" % (shape, err))
     assert err <= 5e-6
+    # ... and both against the float64 oracle (the row-block path of a tall single image and the 3-image batch
+    # met only the layer-by-layer launches before)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    for mode in (1, 0):
+        e = np.abs(outs[mode] - ref).max() / np.abs(ref).max()
+        print("  %s vs float64 oracle: max rel %.3g" % ("streamed" if mode else "layered", e))
+        assert e <= 5e-6
 
 
 # (layers, filters, min_filters, gamma, nin_filters, nin_filters2, scale, activator): between them every instantiated

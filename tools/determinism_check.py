@@ -1,0 +1,62 @@
+"""Is the forward pass bit-reproducible run to run (split16 on / off), alone and with other processes on the same GPU?
+    python tools/determinism_check.py [n_patches] [reps] [tag]"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import dcscn_oracle as O  # noqa: E402
+from dcscn_amd import engine  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+tag = sys.argv[3] if len(sys.argv) > 3 else ""
+cfg = O.make_config(**eval(os.environ.get('DET_CFG', '{}')))
+weights = O.synthetic_weights(cfg, seed=0)
+rng = np.random.default_rng(5)
+x = rng.uniform(0, 255, (96, 48, 48, 1)).astype(np.float32)
+x2 = rng.uniform(0, 255, (96, 96, 96, 1)).astype(np.float32)
+import torch
+xd, x2d = torch.from_numpy(x).cuda(), torch.from_numpy(x2).cuda()
+yd = torch.empty_like(x2d)
+stream = torch.cuda.Stream()
+torch.cuda.synchronize()
+
+
+def fwd_device(eng, lo, cnt):
+    """device buffers, one stream (bench.py's path): excludes the chunked host pipeline of dcscn_forward"""
+    eng.forward_device(xd[lo:lo + cnt].data_ptr(), x2d[lo:lo + cnt].data_ptr(), yd[lo:lo + cnt].data_ptr(), cnt, 48, 48, stream.cuda_stream)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    return yd[lo:lo + cnt].cpu().numpy()
+
+
+modes = [int(m) for m in os.environ.get("DET_MODES", "2,3,0").split(",")]
+host = os.environ.get("DET_HOST") == "1"
+with engine.Engine(cfg, device=0) as eng:
+    eng.load_weights(weights)
+    for s16 in modes:
+        eng.set_option("split16", s16)
+        base = None
+        for lo, cnt in ((0, 96), (0, 32), (32, 32)):
+            digs = set()
+            seq = []
+            y0 = None
+            dmax = 0.0
+            for r in range(reps):
+                y = eng.forward(x[lo:lo + cnt], x2[lo:lo + cnt]) if host else fwd_device(eng, lo, cnt)
+                if y0 is None:
+                    y0 = y.copy()
+                dmax = max(dmax, float(np.abs(y - y0).max()))
+                digs.add(hashlib.sha256(y.tobytes()).hexdigest()[:12])
+                seq.append(hashlib.sha256(y.tobytes()).hexdigest()[:4])
+                per = [hashlib.sha256(y[i].tobytes()).hexdigest()[:8] for i in range(cnt)]
+            if cnt == 96 and lo == 0 and base is None:
+                base = per
+            bad = [lo + i for i in range(cnt) if lo + i < 96 and base[lo + i] != per[i]]
+            print("%s split16=%d patches [%d, %d): %d distinct digests over %d runs (max |diff| between runs %.3g); patches differing from the 96-batch run: %s"
+                  % (tag, s16, lo, lo + cnt, len(digs), reps, dmax, bad[:6]), " ".join(seq), flush=True)

@@ -13,7 +13,6 @@
 #include <vector>
 
 #include "../dcscn-super-resolution_amd/csrc/conv_nin_h.hpp"
-#include "../dcscn-super-resolution_amd/csrc/conv_nin_h2.hpp"
 #include "../dcscn-super-resolution_amd/csrc/split16_pack.hpp"
 #ifdef H16_CONV3
 #include "../dcscn-super-resolution_amd/csrc/conv3_h.hpp"
@@ -113,7 +112,7 @@ static int padded_col(int cc, int nt, int n_full) {
 // ----------------------------------------------------------------------------------------------------------------------
 // conv_nin vs conv_nin_h
 // ----------------------------------------------------------------------------------------------------------------------
-static int g_S = 2;       // input stages of conv_nin_h (NT = 6 cases): argv "nin 3" / "nin 4"
+static int g_S = 3;       // input stages of conv_nin_h: argv "nin 2" / "nin 3"
 struct NinCase { const char* name; long long npix; std::vector<int> widths; int cout; bool multi; };
 
 static int run_nin(const NinCase& C, bool timing, int overflow_test) {
@@ -166,23 +165,20 @@ static int run_nin(const NinCase& C, bool timing, int overflow_test) {
             p32[((size_t)grp * n_chunks + chunk) * 16 * ns + (size_t)row * ns + jn] = dense[(size_t)kp * ctot + pc];
         }
     const int e = split16_scale_exp(dense.data(), dense.size());
-    std::vector<uint16_t> p16 = pack_nin16(dense, n_chunks * 16, ctot, ng, nt, n_chunks, e);
     const int n_chunks32 = (cin_phys + 31) / 32;              // conv_nin_h2: 32-channel chunks, pack_conv16 image with one tap
     std::vector<uint16_t> p16b = pack_conv16(dense, 1, n_chunks * 16, ctot, ng, nt, n_chunks32, e);
     void* d_p16b;
     CK(hipMalloc(&d_p16b, p16b.size() * 2));
     CK(hipMemcpy(d_p16b, p16b.data(), p16b.size() * 2, hipMemcpyHostToDevice));
     float *d_w, *d_p32, *d_bias, *d_alpha, *d_bp, *d_ap, *d_ref, *d_o32, *d_o16;
-    void* d_p16;
     int* d_redo;
     const int out_stride = (cout + 3) & ~3;
     const long long nblocks = (npix + 255) / 256;
-    CK(hipMalloc(&d_w, w.size() * 4)); CK(hipMalloc(&d_p32, p32.size() * 4)); CK(hipMalloc(&d_p16, p16.size() * 2));
+    CK(hipMalloc(&d_w, w.size() * 4)); CK(hipMalloc(&d_p32, p32.size() * 4)); 
     CK(hipMalloc(&d_bias, cout * 4)); CK(hipMalloc(&d_alpha, cout * 4)); CK(hipMalloc(&d_bp, ctot * 4)); CK(hipMalloc(&d_ap, ctot * 4));
     CK(hipMalloc(&d_ref, (size_t)npix * out_stride * 4)); CK(hipMalloc(&d_o32, (size_t)npix * out_stride * 4)); CK(hipMalloc(&d_o16, (size_t)npix * out_stride * 4));
     CK(hipMalloc(&d_redo, nblocks * 4));
     CK(hipMemcpy(d_w, w.data(), w.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_p32, p32.data(), p32.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(d_p16, p16.data(), p16.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_bias, bias.data(), cout * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_alpha, alpha.data(), cout * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_bp, bp.data(), ctot * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_ap, ap.data(), ctot * 4, hipMemcpyHostToDevice));
     CK(hipMemset(d_ref, 0, (size_t)npix * out_stride * 4)); CK(hipMemset(d_o32, 0, (size_t)npix * out_stride * 4)); CK(hipMemset(d_o16, 0, (size_t)npix * out_stride * 4));
@@ -221,7 +217,7 @@ static int run_nin(const NinCase& C, bool timing, int overflow_test) {
     a.N = 1; a.H = 1; a.W = (int)npix;
     a.n_full = nfull; a.split = 1 << 30; a.ps = 1; a.ps_c = 1; a.vec4 = 1;
     a.srctab = d_tab;
-    a.wpack16 = d_p16; a.inv_scale = std::ldexp(1.0f, -e); a.redo = d_redo; a.redo_check = 0;
+    a.wpack16 = d_p16b; a.inv_scale = std::ldexp(1.0f, -e); a.redo = d_redo; a.redo_check = 0;
     const dim3 grid((unsigned)nblocks, (unsigned)ng);
     float ms32 = 0, ms16 = 0;
     const size_t tab_bytes = C.multi ? (size_t)n_chunks * 64 : 0;
@@ -233,33 +229,19 @@ static int run_nin(const NinCase& C, bool timing, int overflow_test) {
         b.redo_check = redo_check ? 1 : 0;
         float ms;
         const int reps = timing ? 5 : 1;
-        if (h16 && g_S >= 12) {                // conv_nin_h2 (K = 32 chunks, 128-pixel blocks): "nin 12" = 2 stages, "nin 13" = 3 stages
+        if (h16) {                             // conv_nin_h (K = 32 chunks, 128-pixel blocks): "nin 2" = 2 input stages, "nin 3" = 3
             b.wpack16 = d_p16b; b.n_chunks = n_chunks32;
             const dim3 grid2((unsigned)((npix + 127) / 128), (unsigned)ng);
             const size_t tab2 = C.multi ? (size_t)n_chunks32 * 128 : 0;
-            if (g_S == 12) {
-                const size_t lds = NinH2Geom<NTc, 2>::LDS_BYTES + tab2;
-                if (C.multi) { auto k = conv_nin_h2<NTc, true, 2>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
-                else { auto k = conv_nin_h2<NTc, false, 2>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
+            if (g_S == 2) {
+                const size_t lds = NinHGeom<NTc, 2>::LDS_BYTES + tab2;
+                if (C.multi) { auto k = conv_nin_h<NTc, true, 2>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
+                else { auto k = conv_nin_h<NTc, false, 2>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
             } else {
-                const size_t lds = NinH2Geom<NTc, 3>::LDS_BYTES + tab2;
-                if (C.multi) { auto k = conv_nin_h2<NTc, true, 3>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
-                else { auto k = conv_nin_h2<NTc, false, 3>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
+                const size_t lds = NinHGeom<NTc, 3>::LDS_BYTES + tab2;
+                if (C.multi) { auto k = conv_nin_h<NTc, true, 3>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
+                else { auto k = conv_nin_h<NTc, false, 3>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid2, lds, b, reps); }
             }
-        } else if (h16 && g_S > 2 && NTc == 6) {      // deeper input prefetch (3 / 4 stages), NT = 6 only
-            if (g_S == 3) {
-                const size_t lds = NinHGeom<6, 3>::LDS_BYTES + tab_bytes;
-                if (C.multi) { auto k = conv_nin_h<6, true, 3>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
-                else { auto k = conv_nin_h<6, false, 3>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
-            } else {
-                const size_t lds = NinHGeom<6, 4>::LDS_BYTES + tab_bytes;
-                if (C.multi) { auto k = conv_nin_h<6, true, 4>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
-                else { auto k = conv_nin_h<6, false, 4>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
-            }
-        } else if (h16) {
-            const size_t lds = NinHGeom<NTc>::LDS_BYTES + tab_bytes;
-            if (C.multi) { auto k = conv_nin_h<NTc, true>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
-            else { auto k = conv_nin_h<NTc, false>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
         } else {
             const size_t lds = NinGeom<NTc>::LDS_BYTES + tab_bytes;
             if (C.multi) { auto k = conv_nin<NTc, true>; CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); ms = time_kernel(k, grid, lds, b, reps); }
@@ -319,7 +301,7 @@ static int run_nin(const NinCase& C, bool timing, int overflow_test) {
     for (float* p : d_src) if (p) CK(hipFree(p));
     if (d_one) CK(hipFree(d_one));
     if (d_tab) CK(hipFree(d_tab));
-    CK(hipFree(d_w)); CK(hipFree(d_p32)); CK(hipFree(d_p16)); CK(hipFree(d_p16b)); CK(hipFree(d_bias)); CK(hipFree(d_alpha)); CK(hipFree(d_bp)); CK(hipFree(d_ap));
+    CK(hipFree(d_w)); CK(hipFree(d_p32)); CK(hipFree(d_p16b)); CK(hipFree(d_bias)); CK(hipFree(d_alpha)); CK(hipFree(d_bp)); CK(hipFree(d_ap));
     CK(hipFree(d_ref)); CK(hipFree(d_o32)); CK(hipFree(d_o16)); CK(hipFree(d_redo));
     return bad;
 }
