@@ -13,7 +13,8 @@ hipError_t c3h_init_kernels() {
     if (e == hipSuccess) e = c3h_set_attr<2>();
     if (e == hipSuccess) e = c3h_set_attr<3>();
     if (e == hipSuccess) e = c3h_set_attr<4>();
-    return e != hipSuccess ? e : c3h_set_attr<5>();
+    if (e == hipSuccess) e = c3h_set_attr<5>();
+    return e != hipSuccess ? e : c3h_set_attr<6>();
 }
 
 // 1-D grid as wino_launch's: groups of one pixel tile congruent mod 8 and close together (conv3_h.hpp)
@@ -39,6 +40,7 @@ hipError_t c3h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t strea
         case 3: return c3h_launch_one<3>(a, n_groups, stream);
         case 4: return c3h_launch_one<4>(a, n_groups, stream);
         case 5: return c3h_launch_one<5>(a, n_groups, stream);
+        case 6: return c3h_launch_one<6>(a, n_groups, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -84,19 +84,20 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
 
     // ---- staging plan of the input image: item = r * 256 + tid = (halo pixel, channel quad) ----
     const int cq = tid & 7;                                   // channel quad of every item of this thread
-    unsigned src_off[G::IN_ROUNDS];                           // byte offset from a_base (without the chunk's channel offset)
-    unsigned ok_mask = 0, col_bits = 0;                       // per item: inside the image; (halo column >> 1) & 3 (2 bits each)
-    static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
-        constexpr int r = decltype(r_)::value;
-        const int hp = r * 32 + (tid >> 3);
-        const int hrow = (hp * 3641) >> 16;                   // hp / 18 for hp < 324 + 32
-        const int hcol = hp - hrow * G::HT;
-        const int gy = y0 - 1 + hrow, gx = x0 - 1 + hcol;
-        const bool ok = hp < G::HP && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        ok_mask |= ok ? (1u << r) : 0u;
-        src_off[r] = (unsigned)((ok ? (hrow * W + hcol) * a.in_stride : (W + 1) * a.in_stride) * 4);
-        col_bits |= (unsigned)((hcol >> 1) & 3) << (2 * r);
-    });
+    // The halo pixel of item r is hp = r * 32 + (tid >> 3): one row and 14 columns further per item.  Its position is re-derived
+    // from tid wherever it is needed (a dozen VALU operations per chunk) instead of living in a register per item.
+    unsigned ok_mask = 0;                                     // per item: inside the image
+    {
+        int hrow = (tid >> 3) >= G::HT ? 1 : 0, hcol = (tid >> 3) - G::HT * hrow;
+        static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            const int gy = y0 - 1 + hrow, gx = x0 - 1 + hcol;
+            const bool ok = r * 32 + (tid >> 3) < G::HP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            ok_mask |= ok ? (1u << r) : 0u;
+            hcol += 32 - G::HT; hrow += 1;
+            if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
+        });
+    }
     const bool all_in = __builtin_amdgcn_readfirstlane((int)(y0 >= 1 && x0 >= 1 && y0 + G::TH + 1 <= H && x0 + G::TW + 1 <= W)) != 0;   // no padding in this tile
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const char* f_base = reinterpret_cast<const char*>(a.wpack16) + (size_t)ntile * a.n_chunks * 9 * G::F_TAP_BYTES;   // wave-uniform
@@ -108,9 +109,16 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
         const unsigned coff = (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4);   // channels past cin: read something valid, written as zeros
         // wave-uniform 64-bit base + 32-bit lane offset: the loads take the SGPR-base form, no 64-bit pointer per item is kept live
         const char* base = reinterpret_cast<const char*>(a_base);
+        int hp0 = tid >> 3;
+        asm volatile("" : "+v"(hp0));                         // keeps the offsets below out of the registers between chunks
+        int hrow = hp0 >= G::HT ? 1 : 0, hcol = hp0 - G::HT * hrow;
+        const int stride4 = a.in_stride * 4;
         static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
             constexpr int r = decltype(r_)::value;
-            gin[r] = *reinterpret_cast<const f32x4*>(base + (size_t)(src_off[r] + coff));
+            const int pix = ((ok_mask >> r) & 1u) ? hrow * W + hcol : W + 1;
+            gin[r] = *reinterpret_cast<const f32x4*>(base + (size_t)((unsigned)(pix * stride4) + coff));
+            hcol += 32 - G::HT; hrow += 1;
+            if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
         });
     };
     const float m1 = opaque_minus_one();
@@ -129,25 +137,30 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
         gin[r] = __builtin_bit_cast(f32x4, u32x4{hu.x, hu.y, lu.x, lu.y});
     };
     auto store_in = [&]() DCSCN_INL {
+        int hp0 = tid >> 3;
+        asm volatile("" : "+v"(hp0));
+        int hcol = hp0 >= G::HT ? hp0 - G::HT : hp0;
         static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
             constexpr int r = decltype(r_)::value;
-            const int hp = r * 32 + (tid >> 3);
+            const int hp = r * 32 + hp0;
             const int kq = cq >> 1;
-            const int unit = (((kq + ((col_bits >> (2 * r)) & 3)) & 3) << 1) | (kq & 1);
+            const int unit = (((kq + ((hcol >> 1) & 3)) & 3) << 1) | (kq & 1);
             const int off = hp * G::PIX_BYTES + unit * 16 + (cq & 1) * 8;
             const u32x4 v = __builtin_bit_cast(u32x4, gin[r]);
             if (r < G::IN_ROUNDS - 1 || hp < G::HP) {
                 *reinterpret_cast<u32x2*>(smem + off) = u32x2{v.x, v.y};
                 *reinterpret_cast<u32x2*>(smem + (off ^ 16)) = u32x2{v.z, v.w};
             }
+            hcol += 32 - G::HT;
+            if (hcol >= G::HT) hcol -= G::HT;
         });
     };
-    // filter pieces of global tap g = chunk * 9 + tap -> ring slot g % 3
-    auto dma_f = [&](int g, int slot) DCSCN_INL {
+    // filter pieces of packed tap `src` (chunk * 9 + ky * 3 + kx in the image) -> ring slot
+    auto dma_f = [&](int src, int slot) DCSCN_INL {
         static_for<0, G::F_ROUNDS>([&](auto r_) DCSCN_INL {
             constexpr int r = decltype(r_)::value;
             const int piece = (wave + 4 * r) % G::F_PIECES;
-            glds16(f_base + (size_t)g * G::F_TAP_BYTES + piece * 1024, f_off, lds0 + G::F_BASE + slot * G::F_TAP_BYTES + (unsigned)piece * 1024u);
+            glds16(f_base + (size_t)src * G::F_TAP_BYTES + piece * 1024, f_off, lds0 + G::F_BASE + slot * G::F_TAP_BYTES + (unsigned)piece * 1024u);
         });
     };
 
@@ -156,19 +169,21 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
         static_for<0, NTV>([&](auto n_) DCSCN_INL { acc[decltype(m_)::value][decltype(n_)::value] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; });
     });
 
-    // B fragment addresses: pixel (row 4w + m + ky, column lj + kx) of the halo tile, channel group lk; one base per tap column
-    int b_hi[3];
-    static_for<0, 3>([&](auto kx_) DCSCN_INL {
+    // B fragment address of tap column kx: pixel (row 4w, column lj + kx) of the halo tile, channel group lk; derived from the
+    // lane at the head of each column (a few VALU operations per three taps, no register per column)
+    auto b_col = [&](auto kx_) DCSCN_INL {
         constexpr int kx = decltype(kx_)::value;
-        const int hx = lj + kx;
-        b_hi[kx] = (4 * wave * G::HT + hx) * G::PIX_BYTES + c3h_unit(hx, lk, 0) * 16;
-    });
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int hx = (l & 15) + kx;
+        return (4 * wave * G::HT + hx) * G::PIX_BYTES + c3h_unit(hx, l >> 4, 0) * 16;
+    };
+    int b_hi = 0;
     const int a_lane = G::F_BASE + lane * 16;
 
     const int n_chunks = a.n_chunks;
-    const int n_taps = n_chunks * 9;
-    dma_f(0, 0);
-    dma_f(1, 1);                                              // n_taps >= 9
+    dma_f(0, 0);                                              // step 0 = tap (ky 0, kx 0), step 1 = tap (ky 1, kx 0)
+    dma_f(3, 1);
     load_in(0);
     static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL { convert_in(r_, 0); });
     store_in();
@@ -183,20 +198,25 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         const bool more = chunk + 1 < n_chunks;                // block uniform
         const int nchunk = more ? chunk + 1 : chunk;
-        static_for<0, 9>([&](auto t_) DCSCN_INL {
-            constexpr int tap = decltype(t_)::value;
-            constexpr int ky = tap / 3, kx = tap % 3;
-            constexpr int slot = tap % 3;                      // (chunk * 9 + tap) % 3
-            const int g = chunk * 9 + tap;
+        // The nine taps go column by column (step s: kx = s / 3, ky = s % 3): down a column the four pixel rows of the wave move
+        // by one row per tap, so only ONE new row of B fragments is read per tap (rows ky .. ky + 3 live in xh / xl[(ky + m) & 3])
+        // -- 12 row reads per column instead of 24; with the 2 NT filter fragments per tap that is 14 LDS reads per 12 NT MFMAs.
+        h8 xh[4], xl[4];
+        static_for<0, 9>([&](auto s_) DCSCN_INL {
+            constexpr int step = decltype(s_)::value;
+            constexpr int kx = step / 3, ky = step % 3;
+            constexpr int slot = step % 3;                     // (chunk * 9 + step) % 3
+            constexpr int step2 = (step + 2) % 9;              // the step two ahead: packed tap (ky2 * 3 + kx2) of this or the next chunk
+            constexpr int ptap2 = (step2 % 3) * 3 + step2 / 3;
             if constexpr (ABL != 3 && ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS) : "memory");
-            if constexpr ((ABL != 4 && ABL != 6) || tap == 0) __syncthreads();
-            if constexpr (ABL != 3 && ABL != 6) dma_f(g + 2 < n_taps ? g + 2 : n_taps - 1, (tap + 2) % 3);
-            if constexpr (tap == 0 && ABL != 2 && ABL != 6) load_in(nchunk);
-            h8 xh[4], xl[4];
-            static_for<0, 4>([&](auto m_) DCSCN_INL {
-                constexpr int m = decltype(m_)::value;
-                xh[m] = *reinterpret_cast<const h8*>(smem + b_hi[kx] + (m + ky) * G::ROW_BYTES);
-                xl[m] = *reinterpret_cast<const h8*>(smem + (b_hi[kx] ^ 16) + (m + ky) * G::ROW_BYTES);
+            if constexpr ((ABL != 4 && ABL != 6) || step == 0) __syncthreads();
+            if constexpr (ABL != 3 && ABL != 6) dma_f((step + 2 < 9 ? chunk : nchunk) * 9 + ptap2, (step + 2) % 3);   // past the end: a re-fetch nobody reads
+            if constexpr (step == 0 && ABL != 2 && ABL != 6) load_in(nchunk);
+            if constexpr (ky == 0) b_hi = b_col(std::integral_constant<int, kx>{});
+            static_for<(ky == 0 ? 0 : 3), 4>([&](auto m_) DCSCN_INL {
+                constexpr int row = ky + decltype(m_)::value;
+                xh[row & 3] = *reinterpret_cast<const h8*>(smem + b_hi + row * G::ROW_BYTES);
+                xl[row & 3] = *reinterpret_cast<const h8*>(smem + (b_hi ^ 16) + row * G::ROW_BYTES);
             });
             const char* fs = smem + a_lane + slot * G::F_TAP_BYTES;
             static_for<0, NTV>([&](auto n_) DCSCN_INL {
@@ -205,16 +225,17 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
                 const h8 wl = *reinterpret_cast<const h8*>(fs + (2 * n + 1) * 1024);
                 static_for<0, 4>([&](auto m_) DCSCN_INL {
                     constexpr int m = decltype(m_)::value;
+                    constexpr int q = (ky + m) & 3;
                     if constexpr (ABL != 5) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[m], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[q], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[q], acc[m][n], 0, 0, 0);
                     }
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[q], acc[m][n], 0, 0, 0);
                 });
             });
-            // the next chunk's input values become (hi, lo) pairs two items per tap from tap 3 on
-            if constexpr (tap >= 3 && ABL != 1 && ABL != 2 && ABL != 6)
-                static_for<2 * (tap - 3), (2 * (tap - 3) + 2 < G::IN_ROUNDS ? 2 * (tap - 3) + 2 : G::IN_ROUNDS)>([&](auto r_) DCSCN_INL { convert_in(r_, nchunk); });
+            // the next chunk's input values become (hi, lo) pairs two items per tap from step 3 on
+            if constexpr (step >= 3 && ABL != 1 && ABL != 2 && ABL != 6)
+                static_for<2 * (step - 3), (2 * (step - 3) + 2 < G::IN_ROUNDS ? 2 * (step - 3) + 2 : G::IN_ROUNDS)>([&](auto r_) DCSCN_INL { convert_in(r_, nchunk); });
         });
         if constexpr (ABL != 1 && ABL != 2 && ABL != 6) {
             if (more) {

@@ -110,7 +110,7 @@ hipError_t nin_h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t str
 // conv3_h.hpp: 3x3 conv + bias + activator (+ depth_to_space) as a direct implicit GEMM; `nt` tiles per group (1..5), groups as for
 // wino_launch; args.wpack16 = pack_conv16 image with 9 taps, args.n_chunks = ceil(cin_phys / 32), args.redo (one flag per 16x16 tile)
 constexpr int kC3hKC = 32;
-constexpr int kC3hMaxNT = 5;
+constexpr int kC3hMaxNT = 6;
 hipError_t c3h_init_kernels();
 hipError_t c3h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
 

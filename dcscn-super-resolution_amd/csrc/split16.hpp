@@ -63,7 +63,7 @@ __device__ __forceinline__ void split8(const f32x4 x, const f32x4 y, float m1, h
 
 __device__ __forceinline__ float opaque_minus_one() {
     float m1 = -1.0f;
-    asm volatile("" : "+v"(m1));
+    asm volatile("" : "+s"(m1));                // a scalar register: the fma takes it as its one SGPR operand
     return m1;
 }
 
