@@ -222,10 +222,10 @@ def is_optimizer_slot(name):
 # (tests/test_checkpoint_writer.py) and TensorFlow's own reader accepts it.
 
 _CRC_TABLE = None
+_CRC_LANES = 16384         # segments whose CRCs advance together in _crc32c's vectorised part (measured: 7 MB in 0.06 s; 4096 lanes 1.4 s)
 
 
-def _crc32c(data, crc=0):
-    """CRC-32C (Castagnoli), table driven; numpy-free so that it also runs on bytes objects of any size."""
+def _crc_table():
     global _CRC_TABLE
     if _CRC_TABLE is None:
         table = []
@@ -234,12 +234,48 @@ def _crc32c(data, crc=0):
             for _ in range(8):
                 c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
             table.append(c)
-        _CRC_TABLE = table
-    table = _CRC_TABLE
-    crc ^= 0xFFFFFFFF
+        _CRC_TABLE = (table, np.asarray(table, dtype=np.uint32))
+    return _CRC_TABLE
+
+
+def _crc_raw(data, state):
+    """The CRC register after ``data`` (no initial / final inversion), byte by byte."""
+    table = _crc_table()[0]
     for b in data:
-        crc = table[(crc ^ b) & 0xFF] ^ (crc >> 8)
-    return crc ^ 0xFFFFFFFF
+        state = table[(state ^ b) & 0xFF] ^ (state >> 8)
+    return state
+
+
+def _crc32c(data, crc=0):
+    """CRC-32C (Castagnoli).  Small inputs: the table loop.  Large ones (a tensor is megabytes): the register update is
+    linear over GF(2), so the buffer is cut into _CRC_LANES equal segments whose registers advance together in numpy
+    (one vector step per byte POSITION, not per byte), and the segment results are chained with the operator "advance the
+    register over len(segment) zero bytes", itself tabulated bytewise from its action on the 32 unit vectors."""
+    data = bytes(data) if not isinstance(data, (bytes, bytearray, memoryview)) else data
+    state = (crc ^ 0xFFFFFFFF) & 0xFFFFFFFF
+    n = len(data)
+    seg = n // _CRC_LANES
+    if seg < 16:
+        return _crc_raw(data, state) ^ 0xFFFFFFFF
+    tnp = _crc_table()[1]
+    body = np.frombuffer(data, dtype=np.uint8, count=seg * _CRC_LANES).reshape(_CRC_LANES, seg)
+    cols = np.ascontiguousarray(body.T).astype(np.uint32)               # [position][segment]
+    regs = np.zeros(_CRC_LANES, dtype=np.uint32)                        # every segment from register 0 (linearity)
+    unit = (np.uint32(1) << np.arange(32, dtype=np.uint32))             # the operator's action on the unit vectors
+    for pos in range(seg):
+        regs = tnp[(regs ^ cols[pos]) & 0xFF] ^ (regs >> 8)
+        unit = tnp[unit & 0xFF] ^ (unit >> 8)
+    # advance(s) = xor of unit[b] over the set bits b of s, as four 256-entry tables
+    adv = []
+    for byte in range(4):
+        t = [0] * 256
+        for v in range(1, 256):
+            low = v & -v
+            t[v] = t[v ^ low] ^ int(unit[8 * byte + low.bit_length() - 1])
+        adv.append(t)
+    for r in regs.tolist():
+        state = adv[0][state & 0xFF] ^ adv[1][(state >> 8) & 0xFF] ^ adv[2][(state >> 16) & 0xFF] ^ adv[3][state >> 24] ^ r
+    return _crc_raw(data[seg * _CRC_LANES:], state) ^ 0xFFFFFFFF
 
 
 def _masked_crc(data):
@@ -259,27 +295,42 @@ def _put_varint(value):
             return bytes(out)
 
 
-def _build_block(items, restart_interval):
-    """LevelDB block: prefix-compressed entries + restart array."""
-    out = bytearray()
-    restarts = []
-    last = b""
-    for i, (key, value) in enumerate(items):
+class _BlockBuilder:
+    """LevelDB block: prefix-compressed entries + restart array (table/block_builder.cc)."""
+
+    def __init__(self, restart_interval):
+        self.interval = restart_interval
+        self.out = bytearray()
+        self.restarts = []
+        self.last = b""
+        self.count = 0
+
+    def add(self, key, value):
         shared = 0
-        if i % restart_interval == 0:
-            restarts.append(len(out))
+        if self.count % self.interval == 0:
+            self.restarts.append(len(self.out))
         else:
-            n = min(len(last), len(key))
-            while shared < n and last[shared] == key[shared]:
+            n = min(len(self.last), len(key))
+            while shared < n and self.last[shared] == key[shared]:
                 shared += 1
-        out += _put_varint(shared) + _put_varint(len(key) - shared) + _put_varint(len(value)) + key[shared:] + value
-        last = key
-    if not restarts:
-        restarts = [0]
-    for r in restarts:
-        out += struct.pack("<I", r)
-    out += struct.pack("<I", len(restarts))
-    return bytes(out)
+        self.out += _put_varint(shared) + _put_varint(len(key) - shared) + _put_varint(len(value)) + key[shared:] + value
+        self.last = key
+        self.count += 1
+
+    def size_estimate(self):
+        """BlockBuilder::CurrentSizeEstimate: what finish() would return -- the table builder's flush criterion."""
+        return len(self.out) + 4 * max(len(self.restarts), 1) + 4
+
+    def finish(self):
+        restarts = self.restarts or [0]
+        return bytes(self.out) + b"".join(struct.pack("<I", r) for r in restarts) + struct.pack("<I", len(restarts))
+
+
+def _build_block(items, restart_interval):
+    b = _BlockBuilder(restart_interval)
+    for key, value in items:
+        b.add(key, value)
+    return b.finish()
 
 
 def _short_successor(key):
@@ -329,21 +380,21 @@ def save_checkpoint(prefix, tensors, block_size=256 << 10):
     out = bytearray()
     index_items = []
 
-    def emit(block_items, next_key):
-        block = _build_block(block_items, 16)
+    def emit(builder, next_key):
+        block = builder.finish()
         handle = _put_varint(len(out)) + _put_varint(len(block))
         out.extend(block + b"\x00" + struct.pack("<I", _masked_crc(block + b"\x00")))
-        last = block_items[-1][0]
+        last = builder.last
         index_items.append((_shortest_separator(last, next_key) if next_key is not None else _short_successor(last), handle))
 
-    pending, pending_bytes = [], 0
+    # TableBuilder::Add: a data block is flushed as soon as its encoded size (entries + restart array) reaches block_size
+    builder = _BlockBuilder(16)
     for i, (key, value) in enumerate(items):
-        pending.append((key, value))
-        pending_bytes += len(key) + len(value) + 3
-        if pending_bytes >= block_size and i + 1 < len(items):
-            emit(pending, items[i + 1][0])
-            pending, pending_bytes = [], 0
-    emit(pending, None)
+        builder.add(key, value)
+        if builder.size_estimate() >= block_size and i + 1 < len(items):
+            emit(builder, items[i + 1][0])
+            builder = _BlockBuilder(16)
+    emit(builder, None)
     meta = _build_block([], 16)
     meta_handle = _put_varint(len(out)) + _put_varint(len(meta))
     out.extend(meta + b"\x00" + struct.pack("<I", _masked_crc(meta + b"\x00")))

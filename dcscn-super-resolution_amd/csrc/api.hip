@@ -411,7 +411,17 @@ int dcscn_resize_bicubic_device(dcscn_handle h, const float* in, float* out, int
     if (n == 0) return DCSCN_OK;
     if (!in || !out) return fail(h, DCSCN_ERR_INVALID_ARG, "null image pointer");
     HIP_TRY(h, hipSetDevice(h->device));
-    return resize_device(h, in, out, n, height, width, out_height, out_width, stream ? (hipStream_t)stream : h->stream);
+    // ordered like a forward (exec.hip: run_forward): behind the previous forward / resize of this handle when that ran on
+    // another stream (the scratch row buffer rs_tmp is shared, and grow() frees it after synchronising `st` only -- which by
+    // then waits for that event too), and recorded so that the next call and dcscn_synchronize see it
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    if (h->has_last && h->last_stream != st) HIP_TRY(h, hipStreamWaitEvent(st, h->done_ev, 0));
+    const int rc = resize_device(h, in, out, n, height, width, out_height, out_width, st);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(h->done_ev, st));
+    h->last_stream = st;
+    h->has_last = true;
+    return DCSCN_OK;
 }
 
 int dcscn_forward_lr(dcscn_handle h, const float* x, float* y, int n, int height, int width) {

@@ -462,6 +462,37 @@ def test_forward_device_alternating_shapes_and_streams(oracle):
         hip.close()
 
 
+def test_forward_device_alternating_streams_on_the_tiled_path(oracle):
+    """the same, through spatial tiling.  With a workspace budget of about 30 x 34 LR pixels both shapes are
+    cut into windows that go through the SHARED tile buffers; the second shape needs larger ones (realloc while the
+    first call may still be running on the other stream).  Every output must equal the synchronised tiled run."""
+    cfg = oracle.make_config(**CONFIGS["L7_F32to8_x2"])
+    weights = oracle.synthetic_weights(cfg, seed=3)
+    shapes = [(1, 64, 50), (2, 90, 77)]
+    data = [synthetic_batch(n, h, w, 2, seed=40 + i) for i, (n, h, w) in enumerate(shapes)]
+    hip = _Hip()
+    try:
+        with _engine(cfg, weights) as eng:
+            eng.forward(*data[0])
+            per_px = eng.workspace_bytes() // (64 * 50) + 1
+            eng.set_option("workspace_budget_bytes", per_px * 30 * 34)
+            expect = [eng.forward(x, x2) for x, x2 in data]                 # tiled, one at a time
+            dev = [(hip.upload(x), hip.upload(x2)) for x, x2 in data]
+            streams = [hip.stream(), hip.stream()]
+            outs = []
+            for it in range(8):
+                k = it & 1
+                n, h, w = shapes[k]
+                y = hip.alloc(expect[k].nbytes)
+                eng.forward_device(dev[k][0], dev[k][1], y, n, h, w, stream=streams[(it // 2) & 1])
+                outs.append((k, y))
+            eng.synchronize()
+            for k, y in outs:
+                assert np.array_equal(hip.download(y, expect[k].shape), expect[k]), "tiled output of an un-synchronised call differs"
+    finally:
+        hip.close()
+
+
 @pytest.mark.parametrize("name", sorted(CONFIGS))
 def test_dense_feature_buffers_are_bit_identical_to_the_concat_tensor(oracle, name):
     """dense_features (default 1): one dense buffer per feature layer and a multi-source NIN GEMM instead of one wide
