@@ -195,9 +195,12 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
     // is hidden, the rest is covered by the other workgroup of the CU).
     // The loads, the conversion and the DMA are unconditional (the last chunk re-reads itself, the last taps re-fetch the last
     // tap): no value in the loop depends on a branch, so the compiler keeps ONE register set for the staged values.
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const int tps = a.tail_tps;                                // 0, or 2 / 4: the last chunk is a paired tail (below)
+    const int n_main = tps ? n_chunks - 1 : n_chunks;
+    for (int chunk = 0; chunk < n_main; ++chunk) {
         const bool more = chunk + 1 < n_chunks;                // block uniform
         const int nchunk = more ? chunk + 1 : chunk;
+        const bool to_tail = tps != 0 && chunk + 1 == n_main;  // the steps two ahead of steps 7, 8 are steps 0, 1 of the paired tail
         // The nine taps go column by column (step s: kx = s / 3, ky = s % 3): down a column the four pixel rows of the wave move
         // by one row per tap, so only ONE new row of B fragments is read per tap (rows ky .. ky + 3 live in xh / xl[(ky + m) & 3])
         // -- 12 row reads per column instead of 24; with the 2 NT filter fragments per tap that is 14 LDS reads per 12 NT MFMAs.
@@ -210,7 +213,8 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
             constexpr int ptap2 = (step2 % 3) * 3 + step2 / 3;
             if constexpr (ABL != 3 && ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS) : "memory");
             if constexpr ((ABL != 4 && ABL != 6) || step == 0) __syncthreads();
-            if constexpr (ABL != 3 && ABL != 6) dma_f((step + 2 < 9 ? chunk : nchunk) * 9 + ptap2, (step + 2) % 3);   // past the end: a re-fetch nobody reads
+            if constexpr (ABL != 3 && ABL != 6)             // past the end: a re-fetch nobody reads; the tail's slots are in step order
+                dma_f(step + 2 < 9 ? chunk * 9 + ptap2 : nchunk * 9 + (to_tail ? step2 : ptap2), (step + 2) % 3);
             if constexpr (step == 0 && ABL != 2 && ABL != 6) load_in(nchunk);
             if constexpr (ky == 0) b_hi = b_col(std::integral_constant<int, kx>{});
             static_for<(ky == 0 ? 0 : 3), 4>([&](auto m_) DCSCN_INL {
@@ -242,6 +246,47 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
                 __syncthreads();                              // every wave is past its last read of this chunk's image
                 store_in();                                   // made visible by the barrier in front of the next tap
             }
+        }
+    }
+    // Paired tail (kernels.h: c3h_tail_tps): the last chunk holds at most 16 / 8 channels, so tps = 2 / 4 taps share one K = 32
+    // instruction -- lane group lk multiplies tap step * tps + lk / (4 / tps), channel octet lk % (4 / tps) of the chunk; the
+    // host packed the filters to match (split16_pack.hpp) and taps past the ninth are zero filters on any valid pixel.
+    // 5 / 3 MFMA steps instead of 9 for the chunk that is mostly padding.
+    if (tps) {
+        const int n_steps = (9 + tps - 1) / tps;
+        const int octs = 4 / tps;
+        const int tail0 = n_main * 9;
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int sub = (l >> 4) / octs, oct = (l >> 4) - sub * octs;
+        for (int step = 0; step < n_steps; ++step) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS) : "memory");
+            __syncthreads();
+            const int slot = step % 3;                         // (tail0 + step) % 3
+            dma_f(tail0 + (step + 2 < n_steps ? step + 2 : n_steps - 1), (step + 2) % 3);
+            int tap = step * tps + sub;
+            tap = tap < 8 ? tap : 8;
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            const int hx = (l & 15) + kx;
+            const int b = ((4 * wave + ky) * G::HT + hx) * G::PIX_BYTES + c3h_unit(hx, oct, 0) * 16;
+            h8 xh[4], xl[4];
+            static_for<0, 4>([&](auto m_) DCSCN_INL {
+                constexpr int m = decltype(m_)::value;
+                xh[m] = *reinterpret_cast<const h8*>(smem + b + m * G::ROW_BYTES);
+                xl[m] = *reinterpret_cast<const h8*>(smem + (b ^ 16) + m * G::ROW_BYTES);
+            });
+            const char* fs = smem + a_lane + slot * G::F_TAP_BYTES;
+            static_for<0, NTV>([&](auto n_) DCSCN_INL {
+                constexpr int n = decltype(n_)::value;
+                const h8 wh = *reinterpret_cast<const h8*>(fs + (2 * n) * 1024);
+                const h8 wl = *reinterpret_cast<const h8*>(fs + (2 * n + 1) * 1024);
+                static_for<0, 4>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[m], acc[m][n], 0, 0, 0);
+                });
+            });
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the clamped re-fetches of the last two taps

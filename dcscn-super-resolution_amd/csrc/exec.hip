@@ -223,6 +223,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         if (op.shape.nin) HIP_TRY(h, nin_h_launch(op.h16.nt, b, op.h16.n_tiles, stream));
         else {
             b.bias = op.h16.d_bias;
+            b.tail_tps = op.h16.tail_tps;
             b.alpha = op.h16.d_alpha;
             HIP_TRY(h, c3h_launch(op.h16.nt, b, op.h16.n_tiles, stream));
         }
