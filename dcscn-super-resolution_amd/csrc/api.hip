@@ -198,7 +198,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     memset(out, 0, sizeof *out);
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
     const bool s16 = h->split16 && op.h16.on && (h->split16_mask & (op.shape.nin ? 2 : 1));
-    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (s16 ? (op.shape.nin ? "conv_nin_h" : "conv3_h") : op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : "depthwise");
+    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (s16 ? (op.shape.nin ? "conv_nin_h" : op.fold_s > 0 ? "conv5_h" : "conv3_h") : op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
     out->out_channels = op.cout;
@@ -217,7 +217,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
             const int64_t tiles = (int64_t)op.h16.n_tiles * (op.h16.nt - 1) + op.h16.n_full;
             out->nt = op.h16.nt; out->kc = 32; out->n_tiles = op.h16.n_tiles;
             // MFMA steps of K = 32: 9 taps per chunk, 5 / 3 in a paired last chunk (conv3_h.hpp)
-            const int64_t ksteps = op.shape.nin ? op.h16.n_chunks
+            const int64_t ksteps = op.shape.nin ? op.h16.n_chunks : op.fold_s > 0 ? 25 * (int64_t)op.h16.n_chunks
                                                 : 9 * (int64_t)(op.h16.n_chunks - (op.h16.tail_tps ? 1 : 0)) + (op.h16.tail_tps ? (9 + op.h16.tail_tps - 1) / op.h16.tail_tps : 0);
             out->executed_macs_per_lr_pixel = r2 * 3 * ksteps * 32 * tiles * 16;
         } else if (op.shape.nin) {

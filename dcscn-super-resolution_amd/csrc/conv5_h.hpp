@@ -1,0 +1,239 @@
+// conv5_h: the folded linear tail (graph.hip: fold_linear_tail -- Up-PS conv + depth_to_space + last reconstruction conv,
+// DCSCN.py:293-323, as ONE 5x5 conv whose 4 s^2 output channels are (sub-pixel phase, border variant)) on
+// v_mfma_f32_16x16x32_f16 at f32 accuracy (split16.hpp).  conv3_h.hpp's scheme with the geometry of a 5x5 window:
+//
+// * workgroup = 4 waves = 16 x 16 LR pixels x NT * 16 channels (NT = ceil(4 s^2 / 16): 1 / 3 / 4 for x2 / x3 / x4), wave w owns
+//   rows 4w..4w+3; halo tile 20 x 20 pixels, written to LDS as conv3_h's B-operand image (same unit swizzle: conflict free for
+//   all five tap columns), 51,200 bytes per 32-channel chunk.
+// * With one or a few output tiles a tap is only 12 NT MFMAs per wave -- too little to pay a barrier for -- so the ring's unit is a
+//   COLUMN of five taps: two slots of 5 * NT * 2 KB, the next column's 10 NT pieces fetched by LDS-DMA while this one computes,
+//   one `vmcnt(0)` + barrier per column (60 NT MFMAs per wave).  Down a column the B rows slide as in conv3_h: 8 + 4 * 2 reads.
+// * LDS = 50 + NT * 20 KB: two workgroups per CU at NT = 1 (x2), one above.
+// * epilogue: conv_igemm's fold epilogue (phase = channel / 4, variant picked by the pixel's position on the image border,
+//   + x2, scalar store to y), accumulators * 2^-e; non-finite accumulators raise redo[tile] for conv_igemm<5,...> behind it.
+#pragma once
+#include "conv3_h.hpp"
+
+namespace dcscn {
+
+template <int NT>
+struct C5HGeom {
+    static constexpr int THREADS = 256;
+    static constexpr int KC = 32;
+    static constexpr int TH = 16, TW = 16;
+    static constexpr int HT = 20;                             // halo tile edge
+    static constexpr int HP = HT * HT;
+    static constexpr int PIX_BYTES = 128;
+    static constexpr int ROW_BYTES = HT * PIX_BYTES;
+    static constexpr int IN_BYTES = HP * PIX_BYTES;           // 51200
+    static constexpr int IN_ITEMS = HP * 8;
+    static constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;   // 13
+    static constexpr int F_TAP_BYTES = NT * 2048;
+    static constexpr int F_COL_BYTES = 5 * F_TAP_BYTES;
+    static constexpr int F_PIECES = 10 * NT;                  // 1 KB DMA pieces of a column
+    static constexpr int F_ROUNDS = (F_PIECES + 3) / 4;
+    static constexpr int F_BASE = IN_BYTES;
+    static constexpr int LDS_BYTES = IN_BYTES + 2 * F_COL_BYTES;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a) {
+    using G = C5HGeom<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem_c5h[];
+    char* smem = smem_c5h;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15;
+    const int lk = lane >> 4;
+
+    const int tile_id = blockIdx.x;
+    int bid = tile_id;
+    const int tx = bid % a.tiles_x;
+    bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int img = bid / a.tiles_y;
+    const int y0 = ty * G::TH;
+    const int x0 = tx * G::TW;
+    const int H = a.H, W = a.W;
+    const float* in_img = a.in + (size_t)img * H * W * a.in_stride + a.in_off;
+    // origin of the halo tile; only in-image addresses are dereferenced (out-of-image items read the tile's own first pixel)
+    const float* a_base = in_img + ((ptrdiff_t)(y0 - 2) * W + (x0 - 2)) * a.in_stride;
+
+    // ---- staging of the input image: item = r * 256 + tid = (halo pixel hp = r * 32 + (tid >> 3), channel quad tid & 7) ----
+    const int cq = tid & 7;
+    unsigned ok_mask = 0;
+    {
+        int hrow = (tid >> 3) >= G::HT ? 1 : 0, hcol = (tid >> 3) - G::HT * hrow;
+        static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            const int gy = y0 - 2 + hrow, gx = x0 - 2 + hcol;
+            const bool ok = r * 32 + (tid >> 3) < G::HP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            ok_mask |= ok ? (1u << r) : 0u;
+            hcol += 32 - G::HT; hrow += 1;
+            if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
+        });
+    }
+    const bool all_in = __builtin_amdgcn_readfirstlane((int)(y0 >= 2 && x0 >= 2 && y0 + G::TH + 2 <= H && x0 + G::TW + 2 <= W)) != 0;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const char* f_base = reinterpret_cast<const char*>(a.wpack16);
+    const unsigned f_off = (unsigned)(lane * 16);
+
+    f32x4 gin[G::IN_ROUNDS];
+    auto load_in = [&](int chunk) DCSCN_INL {
+        const int c0 = chunk * G::KC + cq * 4;
+        const unsigned coff = (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4);
+        const char* base = reinterpret_cast<const char*>(a_base);
+        int hp0 = tid >> 3;
+        asm volatile("" : "+v"(hp0));
+        int hrow = hp0 >= G::HT ? 1 : 0, hcol = hp0 - G::HT * hrow;
+        const int stride4 = a.in_stride * 4;
+        static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            const int pix = ((ok_mask >> r) & 1u) ? hrow * W + hcol : 2 * W + 2;
+            gin[r] = *reinterpret_cast<const f32x4*>(base + (size_t)((unsigned)(pix * stride4) + coff));
+            hcol += 32 - G::HT; hrow += 1;
+            if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
+        });
+    };
+    const float m1 = opaque_minus_one();
+    auto convert_in = [&](auto r_, int chunk) DCSCN_INL {
+        constexpr int r = decltype(r_)::value;
+        f32x4 x = gin[r];
+        const bool whole = all_in && (chunk + 1) * G::KC <= a.cin_phys;
+        if (!whole) {
+            const bool ok = chunk * G::KC + cq * 4 < a.cin_phys && ((ok_mask >> r) & 1u);
+            x.x = ok ? x.x : 0.0f; x.y = ok ? x.y : 0.0f; x.z = ok ? x.z : 0.0f; x.w = ok ? x.w : 0.0f;
+        }
+        h4 hi, lo;
+        split4(x, m1, hi, lo);
+        const u32x2 hu = __builtin_bit_cast(u32x2, hi), lu = __builtin_bit_cast(u32x2, lo);
+        gin[r] = __builtin_bit_cast(f32x4, u32x4{hu.x, hu.y, lu.x, lu.y});
+    };
+    auto store_in = [&]() DCSCN_INL {
+        int hp0 = tid >> 3;
+        asm volatile("" : "+v"(hp0));
+        int hcol = hp0 >= G::HT ? hp0 - G::HT : hp0;
+        static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            const int hp = r * 32 + hp0;
+            const int kq = cq >> 1;
+            const int unit = (((kq + ((hcol >> 1) & 3)) & 3) << 1) | (kq & 1);
+            const int off = hp * G::PIX_BYTES + unit * 16 + (cq & 1) * 8;
+            const u32x4 v = __builtin_bit_cast(u32x4, gin[r]);
+            if (r < G::IN_ROUNDS - 1 || hp < G::HP) {
+                *reinterpret_cast<u32x2*>(smem + off) = u32x2{v.x, v.y};
+                *reinterpret_cast<u32x2*>(smem + (off ^ 16)) = u32x2{v.z, v.w};
+            }
+            hcol += 32 - G::HT;
+            if (hcol >= G::HT) hcol -= G::HT;
+        });
+    };
+    // the 10 NT pieces of tap column kx of a chunk (image: [chunk][tap = ky * 5 + kx][n][hi | lo][1 KB]) -> ring slot
+    auto dma_col = [&](int chunk, int kx, int slot) DCSCN_INL {
+        static_for<0, G::F_ROUNDS>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            const int p = (wave + 4 * r) % G::F_PIECES;       // waves without a piece of their own repeat one
+            const int ky = p / (2 * NT), rem = p - ky * (2 * NT);
+            glds16(f_base + ((size_t)(chunk * 25 + ky * 5 + kx) * (2 * NT) + rem) * 1024, f_off,
+                   lds0 + G::F_BASE + (unsigned)slot * G::F_COL_BYTES + (unsigned)p * 1024u);
+        });
+    };
+
+    f32x4 acc[4][NT];
+    static_for<0, 4>([&](auto m_) DCSCN_INL {
+        static_for<0, NT>([&](auto n_) DCSCN_INL { acc[decltype(m_)::value][decltype(n_)::value] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; });
+    });
+    auto b_col = [&](auto kx_) DCSCN_INL {
+        constexpr int kx = decltype(kx_)::value;
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int hx = (l & 15) + kx;
+        return (4 * wave * G::HT + hx) * G::PIX_BYTES + c3h_unit(hx, l >> 4, 0) * 16;
+    };
+    const int a_lane = G::F_BASE + lane * 16;
+
+    const int n_chunks = a.n_chunks;
+    dma_col(0, 0, 0);
+    load_in(0);
+    static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL { convert_in(r_, 0); });
+    store_in();
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const bool more = chunk + 1 < n_chunks;                // block uniform
+        const int nchunk = more ? chunk + 1 : chunk;
+        static_for<0, 5>([&](auto kx_) DCSCN_INL {
+            constexpr int kx = decltype(kx_)::value;
+            const int slot = (chunk + kx) & 1;                 // (chunk * 5 + kx) & 1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this column's pieces (issued a column ago) and, at kx 1, the input values
+            __syncthreads();                                   // ... of every wave; all waves are past the other slot's column
+            dma_col(kx + 1 < 5 ? chunk : nchunk, (kx + 1) % 5, slot ^ 1);   // past the end: a re-fetch nobody reads
+            if constexpr (kx == 0) load_in(nchunk);
+            const int b_hi = b_col(std::integral_constant<int, kx>{});
+            const char* fcol = smem + a_lane + slot * G::F_COL_BYTES;
+            h8 xh[4], xl[4];
+            static_for<0, 5>([&](auto ky_) DCSCN_INL {
+                constexpr int ky = decltype(ky_)::value;
+                static_for<(ky == 0 ? 0 : 3), 4>([&](auto m_) DCSCN_INL {
+                    constexpr int row = ky + decltype(m_)::value;
+                    xh[row & 3] = *reinterpret_cast<const h8*>(smem + b_hi + row * G::ROW_BYTES);
+                    xl[row & 3] = *reinterpret_cast<const h8*>(smem + (b_hi ^ 16) + row * G::ROW_BYTES);
+                });
+                static_for<0, NT>([&](auto n_) DCSCN_INL {
+                    constexpr int n = decltype(n_)::value;
+                    const h8 wh = *reinterpret_cast<const h8*>(fcol + ky * G::F_TAP_BYTES + (2 * n) * 1024);
+                    const h8 wl = *reinterpret_cast<const h8*>(fcol + ky * G::F_TAP_BYTES + (2 * n + 1) * 1024);
+                    static_for<0, 4>([&](auto m_) DCSCN_INL {
+                        constexpr int m = decltype(m_)::value;
+                        constexpr int q = (ky + m) & 3;
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[q], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[q], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[q], acc[m][n], 0, 0, 0);
+                    });
+                });
+            });
+            // the next chunk's input values become (hi, lo) pairs four items per column from the second column on
+            if constexpr (kx >= 1)
+                static_for<4 * (kx - 1), (4 * kx < G::IN_ROUNDS ? 4 * kx : G::IN_ROUNDS)>([&](auto r_) DCSCN_INL { convert_in(r_, nchunk); });
+        });
+        if (more) {
+            __syncthreads();                                  // every wave is past its last read of this chunk's image
+            store_in();                                       // made visible by the barrier in front of the next column
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the re-fetch of the last column
+
+    // ---- fold epilogue (conv_igemm.hpp): conv channel n * 16 + 4 lk + r = (phase n * 4 + lk, border variant r) ----
+    const int gx = x0 + lj;
+    const int ps = a.ps;
+    const int orow = W * ps;
+    const float inv = a.inv_scale;
+    const float zero = opaque_zero();
+    float chk = 0.0f;
+    float* yout = a.out0.ptr;
+    static_for<0, NT>([&](auto n_) DCSCN_INL {
+        constexpr int n = decltype(n_)::value;
+        const int phase = n * 4 + lk;
+        if (phase < ps * ps && gx < W) {
+            const int pa = phase / ps, pb = phase - pa * ps;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n * 16 + 4 * lk);
+            const bool cb = (pb == 0 && gx == 0) || (pb == ps - 1 && gx == W - 1);
+            static_for<0, 4>([&](auto m_) DCSCN_INL {
+                constexpr int m = decltype(m_)::value;
+                const int gy = y0 + 4 * wave + m;
+                if (gy < H) {
+                    chk = nonfinite_acc(chk, acc[m][n], zero);
+                    const bool rb = (pa == 0 && gy == 0) || (pa == ps - 1 && gy == H - 1);
+                    const f32x4 v = acc[m][n] * inv + bv;
+                    const float lo = cb ? v.y : v.x, hi = cb ? v.w : v.z;
+                    const size_t idx = ((size_t)(img * H + gy) * ps + pa) * orow + (size_t)(gx * ps + pb);
+                    float out = rb ? hi : lo;
+                    if (a.res) out += a.res[idx];
+                    yout[idx] = out;
+                }
+            });
+        }
+    });
+    if (chk != chk && a.redo) a.redo[tile_id] = 1;
+}
+
+}  // namespace dcscn

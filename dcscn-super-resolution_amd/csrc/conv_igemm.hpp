@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256, WPS) void conv_igemm(const ConvArgs a) {
     const int lk = lane >> 4;   // k index within the 4-deep MFMA step / channel quad of the result
 
     int bid = blockIdx.x;
+    if constexpr (G::TH == 16 && G::TW == 16) {
+        if (a.redo_check && a.redo[bid] == 0) return;          // fallback behind conv5_h: only the flagged 16x16 pixel tiles
+    }
     const int tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;

@@ -221,7 +221,10 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         b.n_full = op.h16.n_full;
         b.redo = reinterpret_cast<int32_t*>(static_cast<char*>(h->arena) + h->redo_off) + op.h16.redo_off;
         if (op.shape.nin) HIP_TRY(h, nin_h_launch(op.h16.nt, b, op.h16.n_tiles, stream));
-        else {
+        else if (op.fold_s > 0) {
+            b.bias = op.h16.d_bias;
+            HIP_TRY(h, c5h_launch(op.h16.nt, b, stream));
+        } else {
             b.bias = op.h16.d_bias;
             b.tail_tps = op.h16.tail_tps;
             b.alpha = op.h16.d_alpha;

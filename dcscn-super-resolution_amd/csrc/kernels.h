@@ -120,6 +120,10 @@ inline int c3h_tail_tps(int cin_phys) {
 }
 hipError_t c3h_init_kernels();
 hipError_t c3h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
+// conv5_h (conv5_h.hpp): the folded 5x5 tail on the f16 pipe; nt = ceil(4 ps^2 / 16) in {1, 3, 4}, one channel group, args as conv_launch's
+// fold launch plus args.wpack16 = pack_conv16 image with 25 taps, args.n_chunks = ceil(cin_phys / 32), args.inv_scale, args.redo
+hipError_t c5h_init_kernels();
+hipError_t c5h_launch(int nt, const ConvArgs& args, hipStream_t stream);
 
 // ---- row-streamed feature extractor of the separable narrow nets (feat_stream.hpp) ----
 constexpr int kStreamPX = 48;                  // computed columns per strip: three 16-pixel MFMA tiles

@@ -317,6 +317,31 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     int rc = upload(h, pack.data(), pack.size() * sizeof(float), (void**)&op.d_w);
     if (!rc) rc = upload(h, bias.data(), bias.size() * sizeof(float), (void**)&op.d_bias);
     if (!rc) rc = upload(h, alpha.data(), alpha.size() * sizeof(float), (void**)&op.d_alpha);
+    if (!rc && op.fold_s > 0 && op.ks == 5 && op.shape.mt == 4 && op.segs.size() == 1 && op.dwk == 0) {
+        // conv5_h: the folded tail on the f16 pipe (one channel group of ceil(4 s^2 / 16) tiles; conv_igemm<5, 4, ...> with the
+        // same 16x16 pixel tiles stays behind it as the f32 fallback of flagged tiles)
+        Op::Split16& s16 = op.h16;
+        const ColSeg& sg = op.segs[0];
+        const int cin = (int)op.chan_map.size();
+        const int nt16 = (sg.dst + sg.cout + 15) / 16;
+        if (nt16 == 1 || nt16 == 3 || nt16 == 4) {
+            s16.nt = nt16; s16.n_tiles = 1; s16.n_full = 1;
+            s16.n_chunks = (op.cin_phys + kC3hKC - 1) / kC3hKC;
+            const int ctot16 = nt16 * 16;
+            std::vector<float> dense((size_t)25 * op.cin_phys * ctot16, 0.0f), b16(ctot16, 0.0f);
+            for (int t = 0; t < 25; ++t)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int co = 0; co < sg.cout; ++co)
+                        dense[((size_t)t * op.cin_phys + op.chan_map[ci]) * ctot16 + sg.dst + co] = derived.data[((size_t)t * cin + ci) * sg.cout + co];
+            for (int co = 0; co < sg.cout; ++co) b16[sg.dst + co] = derived_bias[co];
+            const int e = split16_scale_exp(dense.data(), dense.size());
+            s16.inv_scale = std::ldexp(1.0f, -e);
+            const std::vector<uint16_t> img = pack_conv16(dense, 25, op.cin_phys, ctot16, 1, nt16, s16.n_chunks, e);
+            rc = upload(h, img.data(), img.size() * sizeof(uint16_t), &s16.d_w);
+            if (!rc) rc = upload(h, b16.data(), b16.size() * sizeof(float), (void**)&s16.d_bias);
+            s16.on = rc == DCSCN_OK;
+        }
+    }
     return rc;
 }
 

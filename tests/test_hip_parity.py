@@ -314,7 +314,14 @@ def test_folded_tail_borders(oracle, scale, hw):
     ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
     with _fold_engine(cfg, weights) as eng:
         assert len(_folded(eng)) == 1
+        # split16 (default): the composite runs on conv5_h (one / three / four channel tiles for x2 / x3 / x4)
+        assert [op["kernel"] for op in eng.ops() if "(folded)" in op["name"]] == ["conv5_h"]
         y = eng.forward(x, x2)
+    with _fold_engine(cfg, weights) as eng:
+        eng.set_option("split16", 0)
+        assert [op["kernel"] for op in eng.ops() if "(folded)" in op["name"]] == ["conv_igemm"]
+        y32 = eng.forward(x, x2)
+    assert float(np.max(np.abs(y32 - ref))) / float(np.max(np.abs(ref))) <= 1e-5
     with _fold_engine(cfg, weights, fold=False) as eng:
         assert not _folded(eng)
         y0 = eng.forward(x, x2)
