@@ -216,9 +216,9 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
             // f16 multiply-accumulates issued: 3 products, input channels padded to 32, output channels to 16
             const int64_t tiles = (int64_t)op.h16.n_tiles * (op.h16.nt - 1) + op.h16.n_full;
             out->nt = op.h16.nt; out->kc = 32; out->n_tiles = op.h16.n_tiles;
-            // MFMA steps of K = 32: 9 taps per chunk, 5 / 3 in a paired last chunk (conv3_h.hpp)
+            // MFMA steps of K = 32: 9 taps per chunk, 3 / 5 / 7 in a packed last chunk (conv3_h.hpp)
             const int64_t ksteps = op.shape.nin ? op.h16.n_chunks : op.fold_s > 0 ? 25 * (int64_t)op.h16.n_chunks
-                                                : 9 * (int64_t)(op.h16.n_chunks - (op.h16.tail_tps ? 1 : 0)) + (op.h16.tail_tps ? (9 + op.h16.tail_tps - 1) / op.h16.tail_tps : 0);
+                                                : 9 * (int64_t)(op.h16.n_chunks - (op.h16.tail_octs ? 1 : 0)) + (op.h16.tail_octs ? c3h_tail_steps(op.h16.tail_octs) : 0);
             out->executed_macs_per_lr_pixel = r2 * 3 * ksteps * 32 * tiles * 16;
         } else if (op.shape.nin) {
             const int64_t tiles = (int64_t)op.n_tiles * (op.shape.nt - 1) + op.n_full;

@@ -195,12 +195,12 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
     // is hidden, the rest is covered by the other workgroup of the CU).
     // The loads, the conversion and the DMA are unconditional (the last chunk re-reads itself, the last taps re-fetch the last
     // tap): no value in the loop depends on a branch, so the compiler keeps ONE register set for the staged values.
-    const int tps = a.tail_tps;                                // 0, or 2 / 4: the last chunk is a paired tail (below)
-    const int n_main = tps ? n_chunks - 1 : n_chunks;
+    const int octs = a.tail_octs;                              // 0, or 1 / 2 / 3: the last chunk is a packed tail (below)
+    const int n_main = octs ? n_chunks - 1 : n_chunks;
     for (int chunk = 0; chunk < n_main; ++chunk) {
         const bool more = chunk + 1 < n_chunks;                // block uniform
         const int nchunk = more ? chunk + 1 : chunk;
-        const bool to_tail = tps != 0 && chunk + 1 == n_main;  // the steps two ahead of steps 7, 8 are steps 0, 1 of the paired tail
+        const bool to_tail = octs != 0 && chunk + 1 == n_main; // the steps two ahead of steps 7, 8 are steps 0, 1 of the packed tail
         // The nine taps go column by column (step s: kx = s / 3, ky = s % 3): down a column the four pixel rows of the wave move
         // by one row per tap, so only ONE new row of B fragments is read per tap (rows ky .. ky + 3 live in xh / xl[(ky + m) & 3])
         // -- 12 row reads per column instead of 24; with the 2 NT filter fragments per tap that is 14 LDS reads per 12 NT MFMAs.
@@ -248,23 +248,23 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
             }
         }
     }
-    // Paired tail (kernels.h: c3h_tail_tps): the last chunk holds at most 16 / 8 channels, so tps = 2 / 4 taps share one K = 32
-    // instruction -- lane group lk multiplies tap step * tps + lk / (4 / tps), channel octet lk % (4 / tps) of the chunk; the
-    // host packed the filters to match (split16_pack.hpp) and taps past the ninth are zero filters on any valid pixel.
-    // 5 / 3 MFMA steps instead of 9 for the chunk that is mostly padding.
-    if (tps) {
-        const int n_steps = (9 + tps - 1) / tps;
-        const int octs = 4 / tps;
+    // Packed tail (kernels.h: c3h_tail_octs): the last chunk holds at most 8 / 16 / 24 channels = 1 / 2 / 3 octets, so its
+    // (tap, octet) pairs go four to a K = 32 instruction -- lane group lk multiplies pair 4 step + lk = (tap, octet); the host
+    // packed the filters to match (split16_pack.hpp) and pairs past the last are zero filters on any valid pixel.
+    // 3 / 5 / 7 MFMA steps instead of 9 for the chunk that is mostly padding.
+    if (octs) {
+        const int n_steps = (9 * octs + 3) >> 2;
         const int tail0 = n_main * 9;
         int l = lane;
         asm volatile("" : "+v"(l));
-        const int sub = (l >> 4) / octs, oct = (l >> 4) - sub * octs;
         for (int step = 0; step < n_steps; ++step) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS) : "memory");
             __syncthreads();
             const int slot = step % 3;                         // (tail0 + step) % 3
             dma_f(tail0 + (step + 2 < n_steps ? step + 2 : n_steps - 1), (step + 2) % 3);
-            int tap = step * tps + sub;
+            const int pair = 4 * step + (l >> 4);
+            int tap = octs == 1 ? pair : octs == 2 ? pair >> 1 : (pair * 11) >> 5;      // pair / octs for pair < 36
+            const int oct = pair - tap * octs;
             tap = tap < 8 ? tap : 8;
             const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
             const int hx = (l & 15) + kx;

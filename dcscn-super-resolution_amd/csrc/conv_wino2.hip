@@ -12,7 +12,9 @@ static int wino_group_span(int n_groups) { return n_groups < 3 ? n_groups : 3; }
 
 template <int NT>
 static hipError_t wino_set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino2<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, Wino2Geom<NT>::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino2<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, Wino2Geom<NT>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino2_redo<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, Wino2Geom<NT>::LDS_BYTES);
 }
 
 hipError_t wino_init_kernels() {
@@ -30,7 +32,10 @@ static hipError_t wino_launch_one(const ConvArgs& a, int n_groups, hipStream_t s
     b.group_span = env_span > 0 ? (env_span < n_groups ? env_span : n_groups) : wino_group_span(n_groups);
     const int phases = (n_groups + b.group_span - 1) / b.group_span;
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8 * b.group_span * phases));      // 1-D, decoded XCD-aware in the kernel
-    hipLaunchKernelGGL((conv_wino2<NT>), grid, dim3(256), Wino2Geom<NT>::LDS_BYTES, stream, b);
+    if (b.redo_check)                                          // behind conv3_h: 64 tile flags per workgroup (conv_wino2_redo)
+        hipLaunchKernelGGL((conv_wino2_redo<NT>), dim3((unsigned)((tiles + 63) / 64)), dim3(256), Wino2Geom<NT>::LDS_BYTES, stream, b);
+    else
+        hipLaunchKernelGGL((conv_wino2<NT>), grid, dim3(256), Wino2Geom<NT>::LDS_BYTES, stream, b);
     return hipGetLastError();
 }
 

@@ -390,4 +390,31 @@ __global__ __launch_bounds__(256, WPS) void conv_wino2(const ConvArgs a) {
     else if constexpr (NT >= 2) conv_wino2_body<NT, NT - 1, PF, ABL>(a, smem, tile_id, ntile);
 }
 
+// The launch behind conv3_h (split16.hpp): recompute in f32 the pixel tiles whose redo flag is set -- normally none.  A full grid
+// of early exits costs the latency of one flag load per ROUND of workgroups (12-59 us per layer, 0.33 ms per pass of the bench
+// model); here a workgroup reads the flags of 64 tiles at once (one per lane), leaves if none is set, and otherwise walks the
+// flagged tiles and their channel groups.  One workgroup per CU (512 VGPRs allowed): the loop around the body needs more
+// scalar registers than the 2-per-CU kernel has room to spill into.
+template <int NT, int PF = 3>
+__global__ __launch_bounds__(256, 1) void conv_wino2_redo(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n_tiles = a.N * a.tiles_y * a.tiles_x;
+    const int t0 = blockIdx.x * 64;
+    const int lane = threadIdx.x & 63;
+    const int flag = t0 + lane < n_tiles ? a.redo[t0 + lane] : 0;
+    unsigned long long mask = __ballot(flag != 0);            // the same in all four waves
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mask), hi = __builtin_amdgcn_readfirstlane((unsigned)(mask >> 32));
+    mask = ((unsigned long long)hi << 32) | lo;
+    while (mask) {
+        const int tile_id = t0 + __builtin_ctzll(mask);
+        mask &= mask - 1;
+        for (int ntile = 0; ntile < a.n_groups; ++ntile) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // clamped DMAs of the previous body
+            __syncthreads();
+            if (ntile < a.n_full) conv_wino2_body<NT, NT, PF, 0>(a, smem, tile_id, ntile);
+            else if constexpr (NT >= 2) conv_wino2_body<NT, NT - 1, PF, 0>(a, smem, tile_id, ntile);
+        }
+    }
+}
+
 }  // namespace dcscn

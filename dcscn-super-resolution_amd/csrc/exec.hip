@@ -226,7 +226,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
             HIP_TRY(h, c5h_launch(op.h16.nt, b, stream));
         } else {
             b.bias = op.h16.d_bias;
-            b.tail_tps = op.h16.tail_tps;
+            b.tail_octs = op.h16.tail_octs;
             b.alpha = op.h16.d_alpha;
             HIP_TRY(h, c3h_launch(op.h16.nt, b, op.h16.n_tiles, stream));
         }

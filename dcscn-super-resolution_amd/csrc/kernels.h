@@ -63,7 +63,7 @@ struct ConvArgs {
     float inv_scale;          // 2^-e
     int32_t* redo;            // one flag per unit (conv_nin: block of 256 pixels; 3x3: 16x16 pixel tile): a split16 kernel sets
                               // redo[unit] = 1 when an output of the unit is not finite (an activation beyond the f16 range)
-    int32_t tail_tps;         // conv3_h: 0, or 2 / 4 = taps that share one MFMA in the last 32-channel chunk (c3h_tail_tps)
+    int32_t tail_octs;        // conv3_h: 0, or 1 / 2 / 3 = channel octets of the packed last chunk (c3h_tail_octs)
     int32_t redo_check;       // f32 kernels: 1 = run only the units whose flag is set (the launch behind a split16 kernel)
 };
 
@@ -112,12 +112,14 @@ hipError_t nin_h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t str
 // wino_launch; args.wpack16 = pack_conv16 image with 9 taps, args.n_chunks = ceil(cin_phys / 32), args.redo (one flag per 16x16 tile)
 constexpr int kC3hKC = 32;
 constexpr int kC3hMaxNT = 6;
-// conv3_h's paired last chunk: when the last 32-channel chunk holds at most 8 / 16 physical channels, 4 / 2 taps share one
-// K = 32 instruction there (3 / 5 MFMA steps instead of 9); needs a full chunk in front of it
-inline int c3h_tail_tps(int cin_phys) {
+// conv3_h's packed last chunk: when the last 32-channel chunk holds at most 8 / 16 / 24 physical channels (1 / 2 / 3 octets), its
+// (tap, octet) pairs are packed four to a K = 32 instruction -- ceil(9 octets / 4) = 3 / 5 / 7 MFMA steps instead of 9.
+// Returns the octets (0 = plain chunk); needs a full chunk in front of it.
+inline int c3h_tail_octs(int cin_phys) {
     const int n_chunks = (cin_phys + kC3hKC - 1) / kC3hKC, tail = cin_phys - (n_chunks - 1) * kC3hKC;
-    return n_chunks < 2 ? 0 : tail <= 8 ? 4 : tail <= 16 ? 2 : 0;
+    return n_chunks < 2 || tail > 24 ? 0 : (tail + 7) / 8;
 }
+inline int c3h_tail_steps(int octs) { return (9 * octs + 3) / 4; }
 hipError_t c3h_init_kernels();
 hipError_t c3h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
 // conv5_h (conv5_h.hpp): the folded 5x5 tail on the f16 pipe; nt = ceil(4 ps^2 / 16) in {1, 3, 4}, one channel group, args as conv_launch's

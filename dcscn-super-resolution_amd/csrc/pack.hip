@@ -262,8 +262,8 @@ int finalize_op(dcscn_ctx* h, Op& op) {
             }
             const int e = split16_scale_exp(dense.data(), dense.size());
             s16.inv_scale = std::ldexp(1.0f, -e);
-            s16.tail_tps = c3h_tail_tps(op.cin_phys);
-            const std::vector<uint16_t> img = pack_conv16(dense, 9, op.cin_phys, ctot16, s16.n_tiles, nt16, s16.n_chunks, e, s16.tail_tps);
+            s16.tail_octs = c3h_tail_octs(op.cin_phys);
+            const std::vector<uint16_t> img = pack_conv16(dense, 9, op.cin_phys, ctot16, s16.n_tiles, nt16, s16.n_chunks, e, s16.tail_octs);
             rcw = upload(h, img.data(), img.size() * sizeof(uint16_t), &s16.d_w);
             if (!rcw) rcw = upload(h, b16.data(), b16.size() * sizeof(float), (void**)&s16.d_bias);
             if (!rcw) rcw = upload(h, a16.data(), a16.size() * sizeof(float), (void**)&s16.d_alpha);

@@ -108,7 +108,7 @@ struct Op {
         void* d_w = nullptr;                      // pack_conv16 image
         float* d_bias = nullptr;                  // conv3_h: bias / slope in ITS padded group layout (conv_nin_h shares the f32 launch's)
         float* d_alpha = nullptr;
-        int tail_tps = 0;                         // conv3_h: taps per MFMA in the paired last chunk (kernels.h: c3h_tail_tps)
+        int tail_octs = 0;                        // conv3_h: channel octets of the packed last chunk (kernels.h: c3h_tail_octs)
         size_t redo_off = 0;                      // first flag of the op among the pass's redo flags (ensure_workspace)
     } h16;
 };

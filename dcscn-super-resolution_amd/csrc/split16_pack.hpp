@@ -82,25 +82,25 @@ inline std::vector<uint16_t> pack_nin16(const std::vector<float>& dense, int k_r
 
 // conv3_h image: dense [tap][k_rows][cols] -> [group][chunk of 32 channels][tap][n][part: 0 hi, 1 lo][lane = kq * 16 + i][8 halfs]:
 // the A fragments of v_mfma_f32_16x16x32_f16 (row i = output channel, k = 8 kq + t).
-// tail_tps = 2 / 4 (conv3_h's paired last chunk, taps == 9): the last chunk holds at most 16 / 8 real channels, so 2 / 4 taps
-// share one K = 32 instruction -- its tap slot s < ceil(9 / tps) holds, for lane group kq, tap s * tps + kq / (4 / tps) and the
-// channel octet kq % (4 / tps) of the chunk (zeros past tap 8); the other slots of that chunk stay zero and are never fetched.
+// tail_octs = 1 / 2 / 3 (conv3_h's packed last chunk, taps == 9): the last chunk holds at most 8 / 16 / 24 real channels, so its
+// (tap, octet) pairs -- pair p = tap * octs + octet -- are packed four to an instruction: tap slot s < ceil(9 octs / 4) holds, for
+// lane group kq, pair 4 s + kq (zeros past the last pair); the other slots of that chunk stay zero and are never fetched.
 inline std::vector<uint16_t> pack_conv16(const std::vector<float>& dense, int taps, int k_rows, int cols, int n_groups, int nt, int n_chunks, int scale_exp,
-                                         int tail_tps = 0) {
+                                         int tail_octs = 0) {
     std::vector<uint16_t> out((size_t)n_groups * n_chunks * taps * nt * 2 * 64 * 8, 0);
     for (int g = 0; g < n_groups; ++g)
         for (int c = 0; c < n_chunks; ++c) {
-            const bool paired = tail_tps > 0 && c == n_chunks - 1;
-            const int slots = paired ? (taps + tail_tps - 1) / tail_tps : taps;
+            const bool packed = tail_octs > 0 && c == n_chunks - 1;
+            const int slots = packed ? (taps * tail_octs + 3) / 4 : taps;
             for (int slot = 0; slot < slots; ++slot)
                 for (int n = 0; n < nt; ++n)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int i = lane & 15, kq = lane >> 4;
                         uint16_t* hi = &out[((((((size_t)g * n_chunks + c) * taps + slot) * nt + n) * 2 + 0) * 64 + lane) * 8];
                         uint16_t* lo = hi + 64 * 8;
-                        const int octs = paired ? 4 / tail_tps : 4;
-                        const int tap = paired ? slot * tail_tps + kq / octs : slot;
-                        const int oct = paired ? kq % octs : kq;
+                        const int pair = 4 * slot + kq;
+                        const int tap = packed ? pair / tail_octs : slot;
+                        const int oct = packed ? pair % tail_octs : kq;
                         for (int t = 0; t < 8; ++t) {
                             const int k = c * 32 + 8 * oct + t, col = (g * nt + n) * 16 + i;
                             const float w = (k < k_rows && tap < taps) ? dense[((size_t)tap * k_rows + k) * cols + col] : 0.0f;
