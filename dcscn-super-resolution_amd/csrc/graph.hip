@@ -497,7 +497,11 @@ bool fold_linear_tail(dcscn_ctx* h) {
     // worth it only where the composite does less work: 25 taps x (4 s^2 variants padded to 16-channel tiles) per input
     // channel against the shuffler conv's 9 s^2 C (the c-DCSCN nets shuffle to ONE channel: 400 vs 36 -- measured 0.53 ms
     // folded against 0.44 ms layer by layer)
-    if (!h->fold_force && 25 * pad16(4 * u.ps * u.ps) >= 9 * u.ps * u.ps * u.ps_c) return false;
+    // With split16 the composite of an x2 stage (16 channels = ONE tile on conv5_h, two workgroups per CU) wins everywhere, the
+    // c-DCSCN nets included: 0.25 ms against 0.43 (x2), 0.90 against 1.55 for the second stage of x4; at x3 (36 channels, three
+    // tiles, one workgroup per CU) the work rule still decides (0.79 folded against 0.61 for c-DCSCN x3).
+    const bool one_tile_h16 = h->split16 && (h->split16_mask & 1) && u.ps == 2;
+    if (!h->fold_force && !one_tile_h16 && 25 * pad16(4 * u.ps * u.ps) >= 9 * u.ps * u.ps * u.ps_c) return false;
     Op f = u;
     f.name = u.name + "+" + r.name + " (folded)";
     f.ks = 5;

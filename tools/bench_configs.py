@@ -18,6 +18,8 @@ CONFIGS = [
     ("C4-net dcscn_L12_F196to48 x4, 512 patches", dict(scale=4), 512),
     ("C5 dcscn_L7_F32to8 x4 DS, 1024 patches", dict(L7, scale=4, depthwise_separable=True), 1024),
     ("L7 dcscn_L7_F32to8 x2 (c-DCSCN), 1024 patches", dict(L7), 1024),
+    ("L7x3 dcscn_L7_F32to8 x3 (c-DCSCN), 1024 patches", dict(L7, scale=3), 1024),
+    ("L7x4 dcscn_L7_F32to8 x4 (c-DCSCN), 1024 patches", dict(L7, scale=4), 1024),
 ]
 
 
