@@ -54,3 +54,40 @@ def test_uneven_shards():
         assert two["config"]["patches_per_gpu"] == 49
     finally:
         BENCH_ARGS[:] = saved
+
+
+def _evaluate(world, port, tmp_path, ensemble):
+    """evaluate.py on the committed Set5 copy with `world` ranks sharing device 0; returns {file: (psnr, ssim)} at full precision."""
+    golden = os.path.join(ROOT, "tests", "golden")
+    dump = tmp_path / ("dump_%d_%d.txt" % (world, ensemble))
+    env = dict(os.environ, DCSCN_SHARE_GPU="1", DCSCN_EVAL_DUMP=str(dump), MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["--test_dataset=set5", "--layers=2", "--filters=4", "--min_filters=4", "--use_nin=false", "--reconstruct_filters=4",
+            "--self_ensemble=%d" % ensemble, "--save_results=false", "--checkpoint_dir=" + os.path.join(golden, "models"),
+            "--data_dir=" + str(tmp_path / "data"), "--output_dir=" + str(tmp_path / ("out%d" % world)),
+            "--log_filename=" + str(tmp_path / ("log%d.txt" % world))]
+    script = os.path.join(ROOT, "evaluate.py")
+    if world == 1:
+        cmd = [sys.executable, script] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), script] + args
+    out = subprocess.run(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:]
+    res = {}
+    for ln in open(dump):
+        _, name, psnr, ssim = ln.split()
+        res[name] = (psnr, ssim)
+    return res
+
+
+@pytest.mark.parametrize("ensemble", [1, 8])
+def test_evaluate_py_with_two_and_three_ranks_equals_the_one_rank_run(tmp_path, ensemble):
+    """SURVEY 8(e) end to end: evaluate.py shards Set5 by whole images (2 ranks: 5 >= 2 * 2, longest first) or by (image, ensemble
+    transform) items (3 ranks: 5 < 6; with --self_ensemble=8 forty items) -- every PSNR / SSIM must be the one-rank value bit for
+    bit (the ensemble mean is reduced on rank 0 in the reference's order in float64)."""
+    import shutil
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "set5"), tmp_path / "data" / "set5")
+    one = _evaluate(1, 0, tmp_path, ensemble)
+    assert len(one) == 5
+    for world, port in ((2, 29641), (3, 29642)):
+        assert _evaluate(world, port + ensemble, tmp_path, ensemble) == one, "%d-rank evaluate.py differs from the 1-rank run" % world
