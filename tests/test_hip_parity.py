@@ -74,6 +74,31 @@ def test_residual_branch_relative_error(oracle, name, winograd, fold):
     assert rel <= 5e-6
 
 
+@pytest.mark.parametrize("filters", [36, 40, 44, 52, 56, 68, 76, 100, 120])
+def test_conv3_h_packed_last_chunk_channel_counts(oracle, filters):
+    """conv3_h walks K in chunks of 32 channels; a last chunk of at most 8 / 16 / 24 physical channels is packed (tap, octet)
+    pairs four to an MFMA (kernels.h: c3h_tail_octs).  Constant-width nets put exactly `filters` channels into every 3x3 layer:
+    36 / 40 (one octet), 44 / 76 (two: 44 = 32 + 12, 76 = 64 + 12), 52 / 56 / 120 (three), 68 (one, behind two full chunks),
+    100 (one, behind three) -- bare network branch against the float64 oracle at the usual 5e-6, and the same bits as a run with
+    the plain f32 kernels would give to within that bar; ragged image size so that border tiles and the packed chunk meet."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(layers=3, filters=filters, min_filters=filters, nin_filters=32, nin_filters2=16)
+    weights = oracle.synthetic_weights(cfg, seed=31)
+    last = "R-CNN%d" % cfg["reconstruct_layers"]
+    weights[last + "/conv_W"] = weights[last + "/conv_W"] * 100.0
+    x, _ = synthetic_batch(2, 37, 50, 2, seed=32)
+    x2 = np.zeros((2, 74, 100, 1), np.float32)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with engine.Engine(cfg, device=0) as eng:
+        eng.load_weights(weights)
+        kernels = [op["kernel"] for op in eng.ops() if op["kernel_size"] == 3 and op["in_channels"] == filters]
+        assert kernels and all(k == "conv3_h" for k in kernels), eng.ops()
+        y = eng.forward(x, x2)
+    rel = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
+    print("filters=%d: residual-branch relative error %.3g" % (filters, rel))
+    assert np.isfinite(y).all() and rel <= 5e-6
+
+
 def test_baseline_config3_as_written(oracle):
     """BASELINE.json configs[3]: dcscn_L12_F196to48 x4 WITH self_ensemble = 8 on an image-sized input (the 8 flips / rotations
     of DCSCN.py:559-573, four of them transposed, float64 mean) against oracle.do, with split16 on (library default) and off."""
