@@ -49,6 +49,7 @@ MODEL_FLAGS = dict()          # defaults of helper/args.py = dcscn_L12_F196to48_
 MODEL_NAME = "dcscn_L12_F196to48_NIN_A64_PS"
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (at 2.4 GHz)
+SUSTAINED_F16_MFMA_TFLOPS = 2100.0   # measured (tools/mfma_two_waves.hip): 1024 SIMDs x 16384 FLOP / 8.0 ns with the whole chip busy
 PEAK_HBM_GBS = 8000.0
 
 
@@ -376,6 +377,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(executed / dom_peak, 4),
                 "useful_frac": round(dom_useful / (dom_ms * 1e-3) / 1e12 / dom_peak, 4) if dom_ms > 0 else None,
+                "frac_of_sustained": round(executed / SUSTAINED_F16_MFMA_TFLOPS, 4) if on_f16 else None,
                 "traffic": traffic["bytes_per_step"] if traffic else None,
                 "traffic_detail": traffic,
                 "executed_flop_per_step": dom_exec,
@@ -386,9 +388,9 @@ def main():
                                         "MFMA / VALU peak the reference's arithmetic is bound by"},
                 "note": ("achieved = f16 FLOPs the kernel issues (3 products per MAC, input channels padded to 32, output channels to 16) "
                          "per second of its own launch time (HIP events on the launch stream); frac = matrix-pipe utilisation against the "
-                         "dense f16 peak at the nominal 2.4 GHz -- the chip sustains ~1.8 GHz under this kernel (replayed PMC: "
-                         "north_star.conv_3x3.*.sustained_clock_GHz), i.e. ~0.75 of that peak is the power-limited ceiling; useful_frac "
-                         "leaves out the padding." if on_f16 else
+                         "dense f16 peak at the nominal 2.4 GHz; frac_of_sustained = against the 2.1 PFLOP/s the chip sustains with every "
+                         "SIMD issuing bare f16 MFMAs (8.0 ns per MFMA per SIMD = 2.0 GHz, profiles/r03_mfma_two_waves.txt; replayed PMC "
+                         "clock of this kernel: north_star.conv_3x3.*.sustained_clock_GHz); useful_frac leaves out the padding." if on_f16 else
                          "achieved = FLOPs the kernel issues (Winograd F(2x2,3x3): 16/36 of the direct form, plus channel padding to 16 / 8) "
                          "per second of its own launch time (HIP events on the launch stream); frac = matrix-pipe utilisation."),
                 "kernel_ms_per_step": round(dom_ms, 4),
