@@ -21,7 +21,7 @@
 // * filters: f16 (hi, lo) A fragments packed by the host (split16_pack.hpp: pack_conv16) in read order, one tap = NT * 2 KB,
 //   a ring of three tap slots in LDS filled by LDS-DMA (conv_wino2.hpp: glds16) two taps ahead; the wait before a tap's barrier
 //   is a COUNTED vmcnt that leaves the next tap's pieces in flight.
-//   One barrier per tap, two more per chunk around the write of the input image.  LDS = 41.5 + NT * 6 KB: two workgroups per CU.
+//   One barrier per tap, two more per chunk around the write of the input image.  LDS = 41.5 + NT * 6.1 KB: two workgroups per CU.
 // * the chunk's input values are converted to (hi, lo) in registers a few per tap while the chunk's later taps compute (the
 //   f16 MFMA leaves two VALU issue slots per instruction free, profiles/r03_pipe_probe.txt); only the LDS writes sit between
 //   the two barriers of the chunk boundary.
@@ -52,7 +52,8 @@ struct C3HGeom {
     static constexpr int F_ROUNDS = (F_PIECES + 3) / 4;       // DMA instructions per wave and tap (waves without a piece of their own repeat one)
     static constexpr int F_SLOTS = 3;
     static constexpr int F_BASE = IN_BYTES;
-    static constexpr int LDS_BYTES = IN_BYTES + F_SLOTS * F_TAP_BYTES;
+    static constexpr int BA_BASE = IN_BYTES + F_SLOTS * F_TAP_BYTES;   // bias | slopes of the channel group (NT * 16 floats each)
+    static constexpr int LDS_BYTES = BA_BASE + NT * 128;
 };
 
 // position (16-byte unit) of channel group kq, piece `part` (0 hi, 1 lo) inside the record of halo column hx
@@ -102,6 +103,12 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const char* f_base = reinterpret_cast<const char*>(a.wpack16) + (size_t)ntile * a.n_chunks * 9 * G::F_TAP_BYTES;   // wave-uniform
     const unsigned f_off = (unsigned)(lane * 16);
+
+    // bias and slopes of this channel group go to LDS now: read from global memory in the epilogue they are a dependent round trip
+    // (1-2 us) at the end of every workgroup -- 10 % of a narrow layer's workgroup, 1-2 % of a wide one's
+    if (tid < NTV * 4) *reinterpret_cast<f32x4*>(smem + G::BA_BASE + tid * 16) = reinterpret_cast<const f32x4*>(a.bias + ntile * NT * 16)[tid];
+    else if (tid >= 64 && tid < 64 + NTV * 4 && a.act == ACT_ALPHA)
+        *reinterpret_cast<f32x4*>(smem + G::BA_BASE + NT * 64 + (tid - 64) * 16) = reinterpret_cast<const f32x4*>(a.alpha + ntile * NT * 16)[tid - 64];
 
     f32x4 gin[G::IN_ROUNDS];
     auto load_in = [&](int chunk) DCSCN_INL {
@@ -307,9 +314,9 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
         static_for<0, NTV>([&](auto n_) DCSCN_INL {
             constexpr int n = decltype(n_)::value;
             const int c = obase + n * 16;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + cbase + n * 16);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + G::BA_BASE + (n * 4 + lk) * 16);
             f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (act_e == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(a.alpha + cbase + n * 16);
+            if (act_e == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(smem + G::BA_BASE + NT * 64 + (n * 4 + lk) * 16);
             const bool first = c < a.split;
             float* optr = first ? a.out0.ptr : a.out1.ptr;
             const int ostride = first ? a.out0.stride : a.out1.stride;
