@@ -33,7 +33,8 @@ struct C5HGeom {
     static constexpr int F_PIECES = 10 * NT;                  // 1 KB DMA pieces of a column
     static constexpr int F_ROUNDS = (F_PIECES + 3) / 4;
     static constexpr int F_BASE = IN_BYTES;
-    static constexpr int LDS_BYTES = IN_BYTES + 2 * F_COL_BYTES;
+    static constexpr int BA_BASE = IN_BYTES + 2 * F_COL_BYTES;   // the composite's bias terms (NT * 16 floats), staged at workgroup start
+    static constexpr int LDS_BYTES = BA_BASE + NT * 64;
 };
 
 template <int NT>
@@ -78,6 +79,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const char* f_base = reinterpret_cast<const char*>(a.wpack16);
     const unsigned f_off = (unsigned)(lane * 16);
+
+    if (tid < NT * 4) *reinterpret_cast<f32x4*>(smem + G::BA_BASE + tid * 16) = reinterpret_cast<const f32x4*>(a.bias)[tid];   // no global round trip in the epilogue
 
     f32x4 gin[G::IN_ROUNDS];
     auto load_in = [&](int chunk) DCSCN_INL {
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
         const int phase = n * 4 + lk;
         if (phase < ps * ps && gx < W) {
             const int pa = phase / ps, pb = phase - pa * ps;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + n * 16 + 4 * lk);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + G::BA_BASE + (n * 4 + lk) * 16);
             const bool cb = (pb == 0 && gx == 0) || (pb == ps - 1 && gx == W - 1);
             static_for<0, 4>([&](auto m_) DCSCN_INL {
                 constexpr int m = decltype(m_)::value;

@@ -34,7 +34,8 @@ struct NinHGeom {
     static constexpr int B_ROUNDS = (B_PIECES + 3) / 4;
     static constexpr int B_STAGE = B_BYTES;
     static constexpr int B_BASE = S * A_BYTES;
-    static constexpr int LDS_BYTES = S * A_BYTES + 2 * B_STAGE;
+    static constexpr int BA_BASE = S * A_BYTES + 2 * B_STAGE;  // bias | slopes of the channel group (NT * 16 floats each), staged at workgroup start
+    static constexpr int LDS_BYTES = BA_BASE + NT * 128;
     static_assert(S == 2 || S == 3, "2 or 3 input stages");
 };
 
@@ -96,6 +97,10 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
                 *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::LDS_BYTES + 16 * i) = reinterpret_cast<const f32x4*>(a.srctab)[i];
         __syncthreads();
     }
+
+    if (tid < NTV * 4) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::BA_BASE + tid * 16) = reinterpret_cast<const f32x4*>(a.bias + ntile * NT * 16)[tid];
+    else if (tid >= 64 && tid < 64 + NTV * 4 && a.act == ACT_ALPHA)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::BA_BASE + NT * 64 + (tid - 64) * 16) = reinterpret_cast<const f32x4*>(a.alpha + ntile * NT * 16)[tid - 64];
 
     f32x4 acc[G::MT][NTV];
     static_for<0, G::MT>([&](auto m_) DCSCN_INL {
@@ -181,9 +186,9 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
         static_for<0, NTV>([&](auto n_) DCSCN_INL {
             constexpr int n = decltype(n_)::value;
             const int c = obase + n * 16;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + cbase + n * 16);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(smem) + G::BA_BASE + (n * 4 + lk) * 16);
             f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (act_e == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(a.alpha + cbase + n * 16);
+            if (act_e == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(smem) + G::BA_BASE + NT * 64 + (n * 4 + lk) * 16);
             const bool first = c < a.split;
             float* optr = first ? a.out0.ptr : a.out1.ptr;
             const int ostride = first ? a.out0.stride : a.out1.stride;
