@@ -409,16 +409,19 @@ def main():
             cs = min(args.cpu_sample, n)
             xs = x[:cs].cpu().numpy()
             x2s = x2[:cs].cpu().numpy()
-            sec, threads, ycpu = T.time_cpu_path(cfg, weights, xs, x2s, reps=2)
+            sec, threads, ycpu, layout = T.time_cpu_path(cfg, weights, xs, x2s, reps=2)
             dev_err = float(np.max(np.abs(ycpu - y[:cs].cpu().numpy())))
             result["cpu_baseline"] = {
                 "value": round(cs * PATCH * PATCH / sec / 1e6, 5),
                 "unit": "LR Mpix/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": "%d of the %d patches, float32 torch-CPU (oneDNN, NCHW, untuned: a few %% of the host's f32 peak) "
-                          "restatement of the reference graph (TensorFlow not installable), best of 2 after 1 warm-up per thread "
-                          "setting, %.2f s/forward" % (cs, n, sec),
+                "layout": layout,
+                "achieved_gflops": round(sum(o["macs_per_lr_pixel"] for o in ops) * 2.0 * cs * PATCH * PATCH / sec / 1e9, 1),
+                "host_cores": os.cpu_count(),
+                "sample": "%d of the %d patches, float32 torch-CPU (oneDNN; NCHW and channels-last both timed at all host cores and "
+                          "at a quarter of them, the fastest kept: %s, %d threads) restatement of the reference graph (TensorFlow "
+                          "not installable), best of 2 after 1 warm-up per setting, %.2f s/forward" % (cs, n, layout, threads, sec),
                 "max_abs_diff_vs_hip": dev_err,
             }
         if world == 1 and not args.no_host_path:

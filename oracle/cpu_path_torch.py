@@ -15,8 +15,9 @@ import dcscn_oracle as O
 
 
 class TorchCpuModel:
-    def __init__(self, cfg, weights, dtype=torch.float32):
+    def __init__(self, cfg, weights, dtype=torch.float32, channels_last=False):
         self.cfg = cfg
+        self.channels_last = channels_last
         self.ops = O.build_topology(cfg)
         self.dtype = dtype
         self.w = {}
@@ -29,6 +30,8 @@ class TorchCpuModel:
                 t = t.permute(3, 2, 0, 1).contiguous()            # HWIO -> OIHW
             elif leaf == "depthwise_W":
                 t = t.permute(2, 3, 0, 1).contiguous()            # [k,k,C,1] -> [C,1,k,k]
+            if channels_last and t.dim() == 4:
+                t = t.contiguous(memory_format=torch.channels_last)           # oneDNN's NHWC kernels
             self.w[name] = t
 
     @torch.no_grad()
@@ -36,6 +39,8 @@ class TorchCpuModel:
         """x: [N,H,W,1], x2: [N,sH,sW,1] numpy -> [N,sH,sW,1] numpy."""
         t = {"x": torch.from_numpy(np.ascontiguousarray(x)).to(self.dtype).permute(0, 3, 1, 2),
              "x2": torch.from_numpy(np.ascontiguousarray(x2)).to(self.dtype).permute(0, 3, 1, 2)}
+        if self.channels_last:
+            t = {k: v.contiguous(memory_format=torch.channels_last) for k, v in t.items()}
         for op in self.ops:
             kind = op["op"]
             if kind == "conv":
@@ -86,21 +91,24 @@ class TorchCpuModel:
 
 def time_cpu_path(cfg, weights, x, x2, reps=3, threads=None):
     """Times the float32 CPU forward.  ``threads=None`` tries all host cores and a quarter of them
-    (oneDNN convolutions on small patches stop scaling long before 256 threads) and keeps the faster.
-    Returns (seconds per forward (best), threads used, output)."""
+    (oneDNN convolutions on small patches stop scaling long before 256 threads), in NCHW and in channels-last
+    layout, and keeps the fastest.  Returns (seconds per forward (best), threads used, output, layout)."""
     import os
     import time
     cores = os.cpu_count() or 1
     candidates = [threads] if threads else sorted({cores, max(1, cores // 4)}, reverse=True)
-    model = TorchCpuModel(cfg, weights)
-    best, best_threads, y = float("inf"), candidates[0], None
-    for th in candidates:
-        torch.set_num_threads(th)
-        y = model.forward(x, x2)          # warm-up
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            y = model.forward(x, x2)
-            dt = time.perf_counter() - t0
-            if dt < best:
-                best, best_threads = dt, th
-    return best, best_threads, y
+    best, best_threads, best_layout, y = float("inf"), candidates[0], "NCHW", None
+    for layout in ("NCHW", "channels_last"):
+        model = TorchCpuModel(cfg, weights, channels_last=layout == "channels_last")
+        for th in candidates:
+            torch.set_num_threads(th)
+            out = model.forward(x, x2)          # warm-up
+            if y is None:
+                y = out
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                out = model.forward(x, x2)
+                dt = time.perf_counter() - t0
+                if dt < best:
+                    best, best_threads, best_layout, y = dt, th, layout, out
+    return best, best_threads, y, best_layout
