@@ -25,7 +25,11 @@
 // * the chunk's input values are converted to (hi, lo) in registers a few per tap while the chunk's later taps compute (the
 //   f16 MFMA leaves two VALU issue slots per instruction free, profiles/r03_pipe_probe.txt); only the LDS writes sit between
 //   the two barriers of the chunk boundary.
-// * per tap and wave: 8 B-fragment reads + 2 NT A-fragment reads for 12 NT MFMAs (0.28 reads per MFMA at NT = 6).
+// * taps go column by column (kx outer, ky inner): down a column the wave's four pixel rows move by one row per tap, so a tap reads
+//   ONE new B row: per tap and wave 2 (+ 6 at the head of a column) B-fragment reads + 2 NT A-fragment reads for 12 NT MFMAs.
+// * a last chunk with at most 8 / 16 / 24 physical channels is PACKED: its (tap, octet) pairs go four to an instruction, 3 / 5 / 7
+//   MFMA steps instead of 9 (kernels.h: c3h_tail_octs; the host packs the filters to match).
+// * bias and slopes of the channel group are copied to LDS at workgroup start (no global round trip in the epilogue).
 // * epilogue: accumulators * 2^-e, bias, activator, optional depth_to_space addressing, float4 stores; non-finite outputs
 //   raise redo[pixel tile] for the f32 kernel launched behind this one (split16.hpp).
 //
