@@ -450,6 +450,29 @@ def main():
                 }
             except Exception as exc:
                 result["host_path"] = {"error": str(exc)}
+        if world == 1 and not args.no_extra_graph:
+            # beside the headline: the same step replayed from a hipGraph (option graph_replay: captured on the second call with
+            # the same arguments) -- one graph launch instead of the pass's kernel launches
+            try:
+                y_plain = y.clone()
+                eng.set_option("graph_replay", 1)
+                for _ in range(max(args.warmup, 3)):
+                    step()
+                eng.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                eng.synchronize()
+                el4 = time.perf_counter() - t1
+                result["graph_replay"] = {
+                    "value": round(lr_pixels * args.steps / el4 / 1e6, 4), "unit": "LR Mpix/s",
+                    "ms_per_step": round(el4 / args.steps * 1e3, 4),
+                    "bit_identical_to_plain_launches": bool(torch.equal(y, y_plain)),
+                    "note": "dcscn_set_option(graph_replay, 1): opt-in (the pointers must repeat); not the headline",
+                }
+                eng.set_option("graph_replay", 0)
+            except Exception as exc:
+                result["graph_replay"] = {"error": str(exc)}
         if world == 1 and on_f16 and not args.no_extra_graph:
             # beside the headline: the same engine on the pure f32 kernels (split16 = 0), same inputs, timed the same way
             try:

@@ -291,6 +291,15 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
         h->profile = value != 0;
         return DCSCN_OK;
     }
+    if (!strcmp(key, "graph_replay")) {
+        h->graph_replay = value != 0;
+        if (!h->graph_replay && h->graph_exec) {
+            (void)hipGraphExecDestroy(h->graph_exec);
+            h->graph_exec = nullptr;
+        }
+        h->graph_seen = dcscn_ctx::GraphKey{};
+        return DCSCN_OK;
+    }
     return fail(h, DCSCN_ERR_INVALID_ARG, "unknown option '%s'", key);
 }
 
@@ -665,6 +674,7 @@ int dcscn_destroy(dcscn_handle h) {
     (void)hipSetDevice(h->device);
     if (h->has_last) (void)hipStreamSynchronize(h->last_stream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->done_ev) (void)hipEventDestroy(h->done_ev);
     for (hipEvent_t e : h->host_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);

@@ -389,20 +389,71 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         h->ev_used = need;
         h->ev_forwards += 1;
     }
+    // graph replay (option "graph_replay"): the launch sequence below depends only on the arguments and on the arena's carve, so a
+    // forward whose arguments repeat is captured the second time it is seen and replayed afterwards
+    dcscn_ctx::GraphKey gkey;
+    gkey.x = x; gkey.x2 = x2; gkey.y = y; gkey.stream = stream; gkey.n = n; gkey.H = H; gkey.W = W;
+    gkey.split16 = h->split16 ? h->split16_mask : 0;
+    gkey.carve = (unsigned long long)h->carve_gen;
+    const bool graphs = h->graph_replay && !h->profile;
+    bool capturing = false;
+    if (graphs && h->graph_exec && gkey == h->graph_key) {
+        HIP_TRY(h, hipGraphLaunch(h->graph_exec, stream));
+        HIP_TRY(h, hipEventRecord(h->done_ev, stream));
+        h->last_stream = stream;
+        h->has_last = true;
+        return DCSCN_OK;
+    }
+    if (graphs && gkey == h->graph_seen) {
+        HIP_TRY(h, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        capturing = true;
+    }
+    h->graph_seen = gkey;
+    auto abandon_capture = [&]() {
+        if (!capturing) return;
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        capturing = false;
+    };
     for (int b = 0; b < batches; ++b) {
         const int b0 = b * nb;
         const int cnt = std::min(nb, n - b0);
         const float* xb = x + (size_t)b0 * H * W;
         const float* x2b = x2 + (size_t)b0 * H * s * W * s;
         float* yb = y + (size_t)b0 * H * s * W * s;
-        if (h->split16 && h->redo_ints)
-            HIP_TRY(h, hipMemsetAsync(static_cast<char*>(h->arena) + h->redo_off, 0, h->redo_ints * sizeof(int32_t), stream));
+        if (h->split16 && h->redo_ints) {
+            const hipError_t me = hipMemsetAsync(static_cast<char*>(h->arena) + h->redo_off, 0, h->redo_ints * sizeof(int32_t), stream);
+            if (me != hipSuccess) {
+                abandon_capture();
+                HIP_TRY(h, me);
+            }
+        }
         for (int i = 0; i < nops; ++i) {
             if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[ev_base + ((size_t)b * nops + i) * 2], stream));
             rc = launch_op(h, h->ops[i], cnt, H, W, xb, x2b, yb, stream);
-            if (rc) return rc;
+            if (rc) {
+                abandon_capture();
+                return rc;
+            }
             if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[ev_base + ((size_t)b * nops + i) * 2 + 1], stream));
         }
+    }
+    if (capturing) {
+        hipGraph_t g = nullptr;
+        HIP_TRY(h, hipStreamEndCapture(stream, &g));
+        if (h->graph_exec) {
+            (void)hipGraphExecDestroy(h->graph_exec);
+            h->graph_exec = nullptr;
+        }
+        const hipError_t ie = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ie != hipSuccess) {
+            h->graph_exec = nullptr;
+            HIP_TRY(h, ie);
+        }
+        h->graph_key = gkey;
+        HIP_TRY(h, hipGraphLaunch(h->graph_exec, stream));
     }
     HIP_TRY(h, hipEventRecord(h->done_ev, stream));
     h->last_stream = stream;

@@ -164,6 +164,20 @@ struct dcscn_ctx {
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     bool profile = false;
+    // option "graph_replay": a forward whose arguments repeat (same pointers, shape, stream) is captured into a hipGraph the second
+    // time it is seen and replayed from then on -- one graph launch instead of ~30 kernel launches per pass
+    bool graph_replay = false;
+    struct GraphKey {
+        const void *x = nullptr, *x2 = nullptr, *y = nullptr;
+        void* stream = nullptr;
+        int n = 0, H = 0, W = 0, split16 = 0;
+        unsigned long long carve = 0;
+        bool operator==(const GraphKey& o) const {
+            return x == o.x && x2 == o.x2 && y == o.y && stream == o.stream && n == o.n && H == o.H && W == o.W && split16 == o.split16 && carve == o.carve;
+        }
+    };
+    GraphKey graph_seen, graph_key;          // the previous forward's arguments; the arguments graph_exec was captured with
+    hipGraphExec_t graph_exec = nullptr;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
     bool stream_tail = true;                 // the x4 tail of the same nets as one launch (fuse_tail_stream)
     bool stream_features = true;             // separable narrow nets: CNN1 .. B2 as one row-streamed launch (fuse_feat_stream)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--ops", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--graph", action="store_true", help="option graph_replay: the pass replayed from a hipGraph")
     args = ap.parse_args()
     import torch
     import dcscn_oracle as O
@@ -43,9 +44,12 @@ def main():
         x2 = torch.rand((n, 48 * s, 48 * s, 1), device="cuda") * 255
         y = torch.empty_like(x2)
         st = torch.cuda.current_stream().cuda_stream
-        for _ in range(2):
+        if args.graph:
+            eng.set_option("graph_replay", 1)
+        for _ in range(3):
             eng.forward_device(x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, 48, 48, st)
-        eng.set_option("profile", 1)
+        if not args.graph:
+            eng.set_option("profile", 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
