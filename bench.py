@@ -354,8 +354,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
-            "dtype": ("f32-equivalent (3x3 stack and wide 1x1 convs: f16 hi/lo split, 3 products per MAC, f32 accumulate -- error below the "
-                      "f32 kernels'; everything else f32)") if on_f16 else "f32",
+            "dtype": ("f32-equivalent (3x3 stack, wide 1x1 convs and folded tail: f16 hi/lo split, 3 products per MAC, f32 accumulate -- "
+                      "error at the f32 kernels' level, same parity bars; everything else f32)") if on_f16 else "f32",
             "data": "synthetic (uniform 0-255 Y patches, seeded He-init weights; trained L12 blobs are not shipped)",
             "config": {
                 "workload": "%s x2 forward, %s (BASELINE.json configs[2])" % (

@@ -172,7 +172,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * differ by accumulation order only).
  * "split16" (default 1; any time): the 3x3 convs the Winograd kernel would take and the wide 1x1 convs run their contraction
  * on the f16 matrix pipe at f32 accuracy -- every f32 operand as an f16 (hi, lo) pair, three products per MAC, f32
- * accumulation; measured error below the f32 kernels' (profiles/r03_f16x3_numerics.txt).  An activation beyond the f16 range
+ * accumulation; measured error at the f32 kernels' level (profiles/r03_f16x3_numerics.txt).  An activation beyond the f16 range
  * (|x| >= 65520) makes the affected outputs non-finite; the kernel flags their 16x16 tile / 256-pixel block and the f32
  * kernel, launched behind it, recomputes exactly the flagged units -- so the result is f32-exact-safe for any input and does
  * not depend on what else is in the batch.  0 = the pure f32 kernels (conv_wino2 / conv_nin).
