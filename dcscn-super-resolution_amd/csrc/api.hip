@@ -287,6 +287,15 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
         h->split16_mask = value == 2 ? 1 : value == 3 ? 2 : 3;
         return DCSCN_OK;
     }
+    if (!strcmp(key, "debug_digest")) {            // debug aid: a checksum of the whole workspace behind every launch (dcscn_debug_digests)
+        if ((int)h->ops.size() + 1 > 1024) return fail(h, DCSCN_ERR_UNSUPPORTED, "debug_digest: more than 1023 launches");
+        h->debug_digest = value != 0;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "debug_poison")) {            // debug aid (tools/determinism_check.py): no kernel may depend on what LDS / registers held before it
+        h->debug_poison = (int)value;
+        return DCSCN_OK;
+    }
     if (!strcmp(key, "profile")) {
         h->profile = value != 0;
         return DCSCN_OK;
@@ -647,6 +656,16 @@ int dcscn_get_profile(dcscn_handle h, double* ms, int capacity) {
     if (forwards > 1)
         for (double& v : acc) v /= forwards;
     for (int i = 0; i < std::min(capacity, nops); ++i) ms[i] = acc[i];
+    return DCSCN_OK;
+}
+
+int dcscn_debug_digests(dcscn_handle h, uint64_t* out, int capacity) {
+    if (!h) return DCSCN_ERR_INVALID_ARG;
+    if (!out || capacity < 0) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_debug_digests: bad argument");
+    if (!h->d_digest) return fail(h, DCSCN_ERR_STATE, "dcscn_debug_digests: no forward has run with the debug_digest option on");
+    HIP_TRY(h, hipDeviceSynchronize());
+    const int n = std::min(capacity, (int)h->ops.size() + 1);
+    HIP_TRY(h, hipMemcpy(out, h->d_digest, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return DCSCN_OK;
 }
 

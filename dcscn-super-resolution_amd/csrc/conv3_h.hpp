@@ -65,7 +65,9 @@ __host__ __device__ constexpr int c3h_unit(int hx, int kq, int part) { return ((
 
 // ABL (tuner only, tools/h16_tune.hip; results are wrong by design): 0 shipped; 1 no convert + write of the input image after the
 // first chunk; 2 nor its global loads; 3 no filter staging after the first tap; 4 no per-tap barrier; 5 one MFMA product of three;
-// 6 = 2 + 3 + 4 (LDS reads and MFMAs only)
+// 6 = 2 + 3 + 4 (LDS reads and MFMAs only); 7 / 8 = shipped + shader-clock probes (per wave, through a.srctab: [0] entry, [1] K loop
+// start, [2] K loop end, [3] exit, [4] sum over taps of (wait + barrier) [7] or of the DMA / load issue behind it [8], [5] sum of the
+// chunk-boundary barrier + image write, [6] HW_ID)
 template <int NT, int NTV, int ABL = 0>
 __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int tile_id, int ntile) {
     using G = C3HGeom<NT>;
@@ -74,6 +76,9 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15;
     const int lk = lane >> 4;
+    constexpr bool PROBE = ABL == 7 || ABL == 8;
+    long long pr_t0 = 0, pr_t1 = 0, pr_t2 = 0, pr_sum = 0, pr_cb = 0, pr_a = 0;
+    if constexpr (PROBE) pr_t0 = __builtin_readcyclecounter();
 
     int bid = tile_id;
     const int tx = bid % a.tiles_x;
@@ -208,6 +213,7 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
     // tap): no value in the loop depends on a branch, so the compiler keeps ONE register set for the staged values.
     const int octs = a.tail_octs;                              // 0, or 1 / 2 / 3: the last chunk is a packed tail (below)
     const int n_main = octs ? n_chunks - 1 : n_chunks;
+    if constexpr (PROBE) pr_t1 = __builtin_readcyclecounter();
     for (int chunk = 0; chunk < n_main; ++chunk) {
         const bool more = chunk + 1 < n_chunks;                // block uniform
         const int nchunk = more ? chunk + 1 : chunk;
@@ -222,11 +228,15 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
             constexpr int slot = step % 3;                     // (chunk * 9 + step) % 3
             constexpr int step2 = (step + 2) % 9;              // the step two ahead: packed tap (ky2 * 3 + kx2) of this or the next chunk
             constexpr int ptap2 = (step2 % 3) * 3 + step2 / 3;
+            if constexpr (ABL == 7) pr_a = __builtin_readcyclecounter();
             if constexpr (ABL != 3 && ABL != 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::F_ROUNDS) : "memory");
             if constexpr ((ABL != 4 && ABL != 6) || step == 0) __syncthreads();
+            if constexpr (ABL == 7) pr_sum += __builtin_readcyclecounter() - pr_a;
+            if constexpr (ABL == 8) pr_a = __builtin_readcyclecounter();
             if constexpr (ABL != 3 && ABL != 6)             // past the end: a re-fetch nobody reads; the tail's slots are in step order
                 dma_f(step + 2 < 9 ? chunk * 9 + ptap2 : nchunk * 9 + (to_tail ? step2 : ptap2), (step + 2) % 3);
             if constexpr (step == 0 && ABL != 2 && ABL != 6) load_in(nchunk);
+            if constexpr (ABL == 8) pr_sum += __builtin_readcyclecounter() - pr_a;
             if constexpr (ky == 0) b_hi = b_col(std::integral_constant<int, kx>{});
             static_for<(ky == 0 ? 0 : 3), 4>([&](auto m_) DCSCN_INL {
                 constexpr int row = ky + decltype(m_)::value;
@@ -254,8 +264,10 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
         });
         if constexpr (ABL != 1 && ABL != 2 && ABL != 6) {
             if (more) {
+                if constexpr (PROBE) pr_a = __builtin_readcyclecounter();
                 __syncthreads();                              // every wave is past its last read of this chunk's image
                 store_in();                                   // made visible by the barrier in front of the next tap
+                if constexpr (PROBE) pr_cb += __builtin_readcyclecounter() - pr_a;
             }
         }
     }
@@ -301,6 +313,7 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the clamped re-fetches of the last two taps
+    if constexpr (PROBE) pr_t2 = __builtin_readcyclecounter();
 
     // ---- epilogue ----
     const int cbase = ntile * NT * 16 + 4 * lk;                                  // bias / slope index: padded group layout
@@ -356,6 +369,17 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
     else if (act == ACT_NONE) finish(std::integral_constant<int, ACT_NONE>{});
     else finish(std::integral_constant<int, -1>{});
     if (chk != chk && a.redo) a.redo[tile_id] = 1;
+    if constexpr (PROBE) {
+        if (lane == 0 && a.srctab) {
+            long long* pr = reinterpret_cast<long long*>(const_cast<void*>(a.srctab)) + ((size_t)blockIdx.x * 4 + wave) * 8;
+            unsigned hw;
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            pr[7] = xcc;
+            pr[0] = pr_t0; pr[1] = pr_t1; pr[2] = pr_t2; pr[3] = __builtin_readcyclecounter(); pr[4] = pr_sum; pr[5] = pr_cb; pr[6] = hw;
+        }
+    }
 }
 
 // 1-D grid decoded as conv_wino2's: the channel groups of one pixel tile get ids that are congruent mod 8 and close together

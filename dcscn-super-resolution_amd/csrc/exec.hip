@@ -416,6 +416,10 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         if (g) (void)hipGraphDestroy(g);
         capturing = false;
     };
+    if (h->debug_digest) {
+        if (!h->d_digest) HIP_TRY(h, hipMalloc((void**)&h->d_digest, 1024 * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMemsetAsync(h->d_digest, 0, 1024 * sizeof(unsigned long long), stream));
+    }
     for (int b = 0; b < batches; ++b) {
         const int b0 = b * nb;
         const int cnt = std::min(nb, n - b0);
@@ -431,13 +435,28 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         }
         for (int i = 0; i < nops; ++i) {
             if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[ev_base + ((size_t)b * nops + i) * 2], stream));
+            if (h->debug_poison) HIP_TRY(h, debug_poison_launch(h->debug_poison, stream));
             rc = launch_op(h, h->ops[i], cnt, H, W, xb, x2b, yb, stream);
             if (rc) {
                 abandon_capture();
                 return rc;
             }
             if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[ev_base + ((size_t)b * nops + i) * 2 + 1], stream));
+            if (h->debug_digest) {                        // checksum of the buffer(s) this launch writes
+                const Op& op = h->ops[i];
+                for (int k = 0; k < 2; ++k) {
+                    const int idx = op.out_buf[k];
+                    if (k == 1 && idx == op.out_buf[0]) break;
+                    if (idx >= 0) {
+                        const WsBuf& wb = h->bufs[idx];
+                        HIP_TRY(h, debug_digest_launch(static_cast<const char*>(h->arena) + wb.offset, (size_t)cnt * H * wb.res * W * wb.res * wb.stride, h->d_digest + i, stream));
+                    } else if (idx == EXT_Y) {
+                        HIP_TRY(h, debug_digest_launch(yb, (size_t)cnt * H * s * W * s, h->d_digest + i, stream));
+                    }
+                }
+            }
         }
+        if (h->debug_digest) HIP_TRY(h, debug_digest_launch(yb, (size_t)cnt * H * s * W * s, h->d_digest + nops, stream));
     }
     if (capturing) {
         hipGraph_t g = nullptr;

@@ -65,6 +65,7 @@ struct ConvArgs {
                               // redo[unit] = 1 when an output of the unit is not finite (an activation beyond the f16 range)
     int32_t tail_octs;        // conv3_h: 0, or 1 / 2 / 3 = channel octets of the packed last chunk (c3h_tail_octs)
     int32_t redo_check;       // f32 kernels: 1 = run only the units whose flag is set (the launch behind a split16 kernel)
+    int32_t* work;            // conv3_hp (persistent workgroups): the launch's item counter, zero when the launch starts
 };
 
 struct ConvShape {            // kernel variant picked by the plan
@@ -263,5 +264,9 @@ struct DwArgs {
     float* out; int32_t out_stride;   // writes channels [0, cout_phys): logical then zero padding
 };
 hipError_t depthwise_launch(const DwArgs& a, hipStream_t stream);
+// debug (option "debug_poison"): fill the LDS (what & 1) / the vector registers (what & 2) of every CU with NaN patterns
+hipError_t debug_poison_launch(int what, hipStream_t stream);
+// debug (option "debug_digest"): *out += position-weighted checksum of n 32-bit words
+hipError_t debug_digest_launch(const void* p, size_t n_words, unsigned long long* out, hipStream_t stream);
 
 }  // namespace dcscn

@@ -256,6 +256,13 @@ int dcscn_sr_rgb(dcscn_handle h, const uint8_t* rgb, const uint8_t* rgb_upscaled
  * `ms` receives min(capacity, num_ops) entries.  Synchronises the device. */
 int dcscn_get_profile(dcscn_handle h, double* ms, int capacity);
 
+/* Debug aid (no reference counterpart): with dcscn_set_option("debug_digest", 1) every launch of a forward is followed by a
+ * position-weighted checksum of the workspace tensor(s) it writes, and the pass ends with one of its output; `out` receives
+ * min(capacity, num_ops + 1) values of the LAST pass.  Two runs of the same input must agree entry by entry -- the first entry
+ * that differs names the launch whose result changed (tools/determinism_check.py).  "debug_poison" (1 LDS, 2 vector
+ * registers, 3 both) fills those with NaN patterns in front of every launch: no kernel may depend on what they held. */
+int dcscn_debug_digests(dcscn_handle h, uint64_t* out, int capacity);
+
 /* Bytes of device workspace currently held. */
 int64_t dcscn_workspace_bytes(dcscn_handle h);
 

@@ -38,17 +38,32 @@ def fwd_device(eng, lo, cnt):
 modes = [int(m) for m in os.environ.get("DET_MODES", "2,3,0").split(",")]
 host = os.environ.get("DET_HOST") == "1"
 with engine.Engine(cfg, device=0) as eng:
+    for k, v in eval(os.environ.get("DET_OPTS", "{}")).items():      # e.g. {"winograd": 0, "nin_gemm": 0}: every conv on conv_igemm
+        eng.set_option(k, v)
     eng.load_weights(weights)
     for s16 in modes:
         eng.set_option("split16", s16)
         base = None
-        for lo, cnt in ((0, 96), (0, 32), (32, 32)):
+        for lo, cnt in (((0, 96),) if os.environ.get("DET_ONLY96") else ((0, 96), (0, 32), (32, 32))):
             digs = set()
             seq = []
             y0 = None
             dmax = 0.0
+            dig0 = None
             for r in range(reps):
                 y = eng.forward(x[lo:lo + cnt], x2[lo:lo + cnt]) if host else fwd_device(eng, lo, cnt)
+                if os.environ.get("DET_DIGEST"):       # which launch changed?  (DET_OPTS must switch debug_digest on)
+                    d = eng.debug_digests()
+                    if r == 0:
+                        digr0 = d
+                    elif dig0 is None:
+                        dig0 = d                       # baseline = the second run (the first one also carves and clears the workspace)
+                        print("   run 1 vs run 0: differing launches %s" % [i for i in range(len(d)) if d[i] != digr0[i]], flush=True)
+                    else:
+                        first = next((i for i in range(len(d)) if d[i] != dig0[i]), None)
+                        names = [o["name"] + ":" + o["kernel"] for o in eng.ops()] + ["y"]
+                        print("   run %d: first differing launch %s; differing: %s" % (r, None if first is None else names[first],
+                              [names[i] for i in range(len(d)) if d[i] != dig0[i]]), flush=True)
                 if y0 is None:
                     y0 = y.copy()
                 dmax = max(dmax, float(np.abs(y - y0).max()))

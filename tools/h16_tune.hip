@@ -10,12 +10,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <map>
 #include <vector>
 
 #include "../dcscn-super-resolution_amd/csrc/conv_nin_h.hpp"
 #include "../dcscn-super-resolution_amd/csrc/split16_pack.hpp"
 #ifdef H16_CONV3
 #include "../dcscn-super-resolution_amd/csrc/conv3_h.hpp"
+#include "../dcscn-super-resolution_amd/csrc/conv3_hp.hpp"
 #endif
 
 using namespace dcscn;
