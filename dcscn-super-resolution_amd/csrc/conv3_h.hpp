@@ -36,6 +36,9 @@
 #pragma once
 #include "conv_wino2.hpp"
 #include "split16.hpp"
+#ifndef C3H_EXP
+#define C3H_EXP 0
+#endif
 
 namespace dcscn {
 
@@ -244,6 +247,7 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
                 xl[row & 3] = *reinterpret_cast<const h8*>(smem + (b_hi ^ 16) + row * G::ROW_BYTES);
             });
             const char* fs = smem + a_lane + slot * G::F_TAP_BYTES;
+#if C3H_EXP == 0
             static_for<0, NTV>([&](auto n_) DCSCN_INL {
                 constexpr int n = decltype(n_)::value;
                 const h8 wh = *reinterpret_cast<const h8*>(fs + (2 * n) * 1024);
@@ -258,6 +262,33 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[q], acc[m][n], 0, 0, 0);
                 });
             });
+#else
+            // experiment (tools/h16_tune, -DC3H_EXP=1/3): products outermost per tile (an accumulator is touched every 4th MFMA);
+            // bit 1: the A fragments of tile n + 1 are read into a second register pair before tile n's MFMAs, order pinned
+            {
+                h8 whb[2], wlb[2];
+                whb[0] = *reinterpret_cast<const h8*>(fs);
+                wlb[0] = *reinterpret_cast<const h8*>(fs + 1024);
+                static_for<0, NTV>([&](auto n_) DCSCN_INL {
+                    constexpr int n = decltype(n_)::value;
+                    constexpr int cb = (C3H_EXP & 2) ? (n & 1) : 0;
+                    if constexpr ((C3H_EXP & 2) != 0) {
+                        if constexpr (n + 1 < NTV) {
+                            whb[(n + 1) & 1] = *reinterpret_cast<const h8*>(fs + (2 * n + 2) * 1024);
+                            wlb[(n + 1) & 1] = *reinterpret_cast<const h8*>(fs + (2 * n + 3) * 1024);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        }
+                    } else if constexpr (n > 0) {
+                        whb[0] = *reinterpret_cast<const h8*>(fs + (2 * n) * 1024);
+                        wlb[0] = *reinterpret_cast<const h8*>(fs + (2 * n + 1) * 1024);
+                    }
+                    static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlb[cb], xh[(ky + m) & 3], acc[m][n], 0, 0, 0); });
+                    static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whb[cb], xl[(ky + m) & 3], acc[m][n], 0, 0, 0); });
+                    static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whb[cb], xh[(ky + m) & 3], acc[m][n], 0, 0, 0); });
+                    if constexpr ((C3H_EXP & 2) != 0) __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                });
+            }
+#endif
             // the next chunk's input values become (hi, lo) pairs two items per tap from step 3 on
             if constexpr (step >= 3 && ABL != 1 && ABL != 2 && ABL != 6)
                 static_for<2 * (step - 3), (2 * (step - 3) + 2 < G::IN_ROUNDS ? 2 * (step - 3) + 2 : G::IN_ROUNDS)>([&](auto r_) DCSCN_INL { convert_in(r_, nchunk); });

@@ -39,11 +39,18 @@ struct C3PGeom : C3HGeom<NT> {
 };
 
 struct C3Item {
-    int valid, tile_id, ntile, img, y0, x0;
+    int id, valid, tile_id, ntile, img, y0, x0;
     bool all_in, full;
     const char* a_base;      // origin of the halo tile (only in-image addresses are dereferenced)
     const char* f_base;      // the channel group's filter image
     unsigned ok_mask;        // per thread: staged item r lies inside the image
+};
+struct C3Next {              // what the item in progress needs to know about the one behind it: where its first image chunk and taps are
+    int id, valid;
+    bool all_in;
+    const char* a_base;
+    const char* f_base;
+    unsigned ok_mask;
 };
 
 template <int N>
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
     const int lk = lane >> 4;
     const int H = a.H, W = a.W;
     const int n_groups = a.n_groups;
-    const int n_items = a.N * a.tiles_y * a.tiles_x * n_groups;
+    const int n_tiles = a.N * a.tiles_y * a.tiles_x;
     const int n_chunks = a.n_chunks;
     const int octs = a.tail_octs;                              // 0, or 1 / 2 / 3: the last chunk is a packed tail
     const int n_main = octs ? n_chunks - 1 : n_chunks;
@@ -82,39 +89,57 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
     if constexpr (DBG == 1) pr_t0 = __builtin_readcyclecounter();
 
     // ---- items ----
-    auto decode = [&](int id, C3Item& it) DCSCN_INL {
-        it.valid = id < n_items;
-        const int idc = it.valid ? id : 0;                     // past the end: a valid item nobody computes (its prefetches are harmless)
-        const int tile_id = idc / n_groups;
-        it.tile_id = tile_id;
-        it.ntile = idc - tile_id * n_groups;
+    auto decode = [&](int id, auto& it, auto full_c) DCSCN_INL {
+        constexpr bool FULLREC = decltype(full_c)::value;
+        // id = 8 k + x: the k-th item of XCD x's queue = channel group k % n_groups of pixel tile 8 (k / n_groups) + x -- the groups of one
+        // tile are taken by workgroups of one XCD at about the same time and share the tile's input through that L2
+        it.id = id;
+        const int k = id >> 3, tl = k / n_groups;
+        int tile_id = tl * 8 + (id & 7);
+        int ntile = k - tl * n_groups;
+        it.valid = tile_id < n_tiles;
+        if (!it.valid) { tile_id = 0; ntile = 0; }            // past the end: a valid item nobody computes (its prefetches are harmless)
         int bid = tile_id;
         const int tx = bid % a.tiles_x;
         bid /= a.tiles_x;
         const int ty = bid % a.tiles_y;
-        it.img = bid / a.tiles_y;
-        it.y0 = ty * G::TH;
-        it.x0 = tx * G::TW;
-        it.all_in = it.y0 >= 1 && it.x0 >= 1 && it.y0 + G::TH + 1 <= H && it.x0 + G::TW + 1 <= W;
-        it.full = it.y0 + G::TH <= H && it.x0 + G::TW <= W;
-        it.a_base = reinterpret_cast<const char*>(a.in + (size_t)it.img * H * W * a.in_stride + a.in_off + ((ptrdiff_t)(it.y0 - 1) * W + (it.x0 - 1)) * a.in_stride);
-        it.f_base = reinterpret_cast<const char*>(a.wpack16) + (size_t)it.ntile * n_chunks * 9 * G::F_TAP_BYTES;
+        const int img = bid / a.tiles_y;
+        const int y0 = ty * G::TH, x0 = tx * G::TW;
+        if constexpr (FULLREC) {
+            it.tile_id = tile_id; it.ntile = ntile; it.img = img; it.y0 = y0; it.x0 = x0;
+            it.full = y0 + G::TH <= H && x0 + G::TW <= W;
+        }
+        it.all_in = y0 >= 1 && x0 >= 1 && y0 + G::TH + 1 <= H && x0 + G::TW + 1 <= W;
+        it.a_base = reinterpret_cast<const char*>(a.in + (size_t)img * H * W * a.in_stride + a.in_off + ((ptrdiff_t)(y0 - 1) * W + (x0 - 1)) * a.in_stride);
+        it.f_base = reinterpret_cast<const char*>(a.wpack16) + (size_t)ntile * n_chunks * 9 * G::F_TAP_BYTES;
         unsigned m = 0;
-        int hrow = (tid >> 3) >= G::HT ? 1 : 0, hcol = (tid >> 3) - G::HT * hrow;
+        int hp0 = tid >> 3;
+        asm volatile("" : "+v"(hp0));                          // re-derived per item: hoisted out of the item loop the 22 positions stay in registers
+        int hrow = hp0 >= G::HT ? 1 : 0, hcol = hp0 - G::HT * hrow;
         static_for<0, L>([&](auto r_) DCSCN_INL {
             constexpr int r = decltype(r_)::value;
-            const int gy = it.y0 - 1 + hrow, gx = it.x0 - 1 + hcol;
-            const bool ok = r * 32 + (tid >> 3) < G::HP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const int gy = y0 - 1 + hrow, gx = x0 - 1 + hcol;
+            const bool ok = r * 32 + hp0 < G::HP && gy >= 0 && gy < H && gx >= 0 && gx < W;
             m |= ok ? (1u << r) : 0u;
             hcol += 32 - G::HT; hrow += 1;
             if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
         });
         it.ok_mask = m;
     };
-    // lane 0 of every wave issues the atomic (the same count of vector-memory operations in every wave); wave 0's takes `n` items
+    // Items are dealt per XCD: counter x (one cache line each) hands out k = 0, 1, ... and k stands for item 8 k + x -- 64 workgroups per
+    // counter instead of 512 on one word (an agent-scope atomic is ~12 ns of a serialised L2 resource: one shared counter, fetched by
+    // 2048 waves per round of items, cost ~50 k cycles per item).  Wave 0 does the atomic; the other waves issue a plain load of a
+    // read-only word instead, so that every wave has the same count of vector-memory operations in flight.
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    int* const my_counter = a.work + xcc * 16;
     auto fetch = [&](int n) DCSCN_INL -> int {
         int got = 0;
-        if (lane == 0) got = __hip_atomic_fetch_add(a.work, wave == 0 ? n : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            if (wave == 0) got = __hip_atomic_fetch_add(my_counter, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8 + (int)xcc;
+            else got = *reinterpret_cast<const volatile int*>(a.bias);
+        }
         return got;
     };
     auto post = [&](int v) DCSCN_INL { if (tid == 0) *reinterpret_cast<volatile int*>(smem + G::MAIL) = v; };
@@ -122,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
 
     // ---- staging of an input image chunk: item = r * 256 + tid = (halo pixel, channel quad), conv3_h.hpp ----
     f32x4 gin[L];
-    auto load_in = [&](const C3Item& it, int chunk) DCSCN_INL {
+    auto load_in = [&](const char* it_a_base, unsigned it_ok_mask, int chunk) DCSCN_INL {
         const int c0 = chunk * G::KC + cq * 4;
         const unsigned coff = (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4);
         int hp0 = tid >> 3;
@@ -131,19 +156,19 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
         const int stride4 = a.in_stride * 4;
         static_for<0, L>([&](auto r_) DCSCN_INL {
             constexpr int r = decltype(r_)::value;
-            const int pix = ((it.ok_mask >> r) & 1u) ? hrow * W + hcol : W + 1;
-            gin[r] = *reinterpret_cast<const f32x4*>(it.a_base + (size_t)((unsigned)(pix * stride4) + coff));
+            const int pix = ((it_ok_mask >> r) & 1u) ? hrow * W + hcol : W + 1;
+            gin[r] = *reinterpret_cast<const f32x4*>(it_a_base + (size_t)((unsigned)(pix * stride4) + coff));
             hcol += 32 - G::HT; hrow += 1;
             if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
         });
     };
     const float m1 = opaque_minus_one();
-    auto convert_in = [&](auto r_, const C3Item& it, int chunk) DCSCN_INL {
+    auto convert_in = [&](auto r_, bool it_all_in, unsigned it_ok_mask, int chunk) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
         f32x4 x = gin[r];
-        const bool whole = it.all_in && (chunk + 1) * G::KC <= a.cin_phys;       // block uniform: nothing to zero
+        const bool whole = it_all_in && (chunk + 1) * G::KC <= a.cin_phys;       // block uniform: nothing to zero
         if (!whole) {
-            const bool ok = chunk * G::KC + cq * 4 < a.cin_phys && ((it.ok_mask >> r) & 1u);
+            const bool ok = chunk * G::KC + cq * 4 < a.cin_phys && ((it_ok_mask >> r) & 1u);
             x.x = ok ? x.x : 0.0f; x.y = ok ? x.y : 0.0f; x.z = ok ? x.z : 0.0f; x.w = ok ? x.w : 0.0f;
         }
         h4 hi, lo;
@@ -187,7 +212,8 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
     };
 
     // ---- start: three item ids, the first item's image and first two taps ----
-    C3Item cur, nxt;
+    C3Item cur;
+    C3Next nxt;
     int nn_id;
     int fetched = 0;
     {
@@ -196,24 +222,26 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         c3p_barrier();
         const int id0 = collect();
-        decode(id0, cur);
-        decode(id0 + 1, nxt);
-        nn_id = id0 + 2;
+        decode(id0, cur, std::true_type{});
+        decode(id0 + 8, nxt, std::false_type{});
+        nn_id = id0 + 16;
         fetched = nn_id;                                      // what the first item posts at step 3 (afterwards: the previous epilogue's fetch)
     }
     if (!cur.valid) return;
     int s0 = G::F_BASE, s1 = G::F_BASE + G::F_TAP_BYTES, s2 = G::F_BASE + 2 * G::F_TAP_BYTES;      // ring slots of steps 0, 1, 2 (mod 3)
     dma_f(cur.f_base, s0);                                    // step 0 = tap (ky 0, kx 0), step 1 = tap (ky 1, kx 0) = packed tap 3
     dma_f(cur.f_base + 3 * G::F_TAP_BYTES, s1);
-    load_in(cur, 0);
-    static_for<0, L>([&](auto r_) DCSCN_INL { convert_in(r_, cur, 0); });
+    load_in(cur.a_base, cur.ok_mask, 0);
+    static_for<0, L>([&](auto r_) DCSCN_INL { convert_in(r_, cur.all_in, cur.ok_mask, 0); });
     store_in();
     bool extra = false;                                       // the previous epilogue issued (at least) E_FULL operations behind the tap DMAs
     int parity = 0;
 
-    // ---- one item: K loop + epilogue, with NTV = NT or NT - 1 channel tiles ----
-    auto run_item = [&](auto ntv_c) DCSCN_INL {
-        constexpr int NTV = decltype(ntv_c)::value;
+    // ---- one item: K loop + epilogue.  A narrow channel group (ntile >= n_full) has NT - 1 tiles: its last tile is skipped under a
+    // block-uniform branch (one body for both kinds of group: two instantiations of this loop nest cost ~60 VGPRs in hoisted addresses)
+    auto run_item = [&]() DCSCN_INL {
+        constexpr int NTV = NT;
+        const bool wide = NT == 1 || cur.ntile < a.n_full;
         const int ba = G::BA0 + parity * G::BA_BYTES;
         if (tid < NTV * 4) *reinterpret_cast<f32x4*>(smem + ba + tid * 16) = reinterpret_cast<const f32x4*>(a.bias + cur.ntile * NT * 16)[tid];
         else if (tid >= 64 && tid < 64 + NTV * 4 && a.act == ACT_ALPHA)
@@ -230,7 +258,9 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
             const bool last_main = chunk + 1 == n_main;
             const bool ends = last_main && octs == 0;           // what follows this chunk is the next item
             const bool first = chunk == 0 && extra;
-            const C3Item& li = ends ? nxt : cur;                // whose image is loaded during this chunk
+            const char* li_a_base = ends ? nxt.a_base : cur.a_base;      // whose image is loaded during this chunk
+            const unsigned li_ok = ends ? nxt.ok_mask : cur.ok_mask;
+            const bool li_all_in = ends ? nxt.all_in : cur.all_in;
             const int lchunk = ends ? 0 : chunk + 1;
             h8 xh[4], xl[4];
             static_for<0, 9>([&](auto s_) DCSCN_INL {
@@ -257,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
                                          : nxt.f_base + (size_t)ptap2 * G::F_TAP_BYTES;
                     dma_f(src, slot2);
                 }
-                if constexpr (step == 0) load_in(li, lchunk);
+                if constexpr (step == 0) load_in(li_a_base, li_ok, lchunk);
                 if constexpr (step == 3) { if (chunk == 0) post(fetched); }          // the item id fetched by the previous epilogue has arrived
                 if constexpr (step == 5) { if (chunk == 0) nn_id = collect(); }
                 if constexpr (ky == 0) b_hi = b_col(std::integral_constant<int, kx>{});
@@ -269,19 +299,21 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
                 const char* fs = smem + a_lane + slot;
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
                     constexpr int n = decltype(n_)::value;
-                    const h8 wh = *reinterpret_cast<const h8*>(fs + (2 * n) * 1024);
-                    const h8 wl = *reinterpret_cast<const h8*>(fs + (2 * n + 1) * 1024);
-                    static_for<0, 4>([&](auto m_) DCSCN_INL {
-                        constexpr int m = decltype(m_)::value;
-                        constexpr int q = (ky + m) & 3;
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[q], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[q], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[q], acc[m][n], 0, 0, 0);
-                    });
+                    if (n < NT - 1 || wide) {
+                        const h8 wh = *reinterpret_cast<const h8*>(fs + (2 * n) * 1024);
+                        const h8 wl = *reinterpret_cast<const h8*>(fs + (2 * n + 1) * 1024);
+                        static_for<0, 4>([&](auto m_) DCSCN_INL {
+                            constexpr int m = decltype(m_)::value;
+                            constexpr int q = (ky + m) & 3;
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[q], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[q], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[q], acc[m][n], 0, 0, 0);
+                        });
+                    }
                 });
                 // the image in flight becomes (hi, lo) pairs two items per tap from step 3 on
                 if constexpr (step >= 3)
-                    static_for<2 * (step - 3), (2 * (step - 3) + 2 < L ? 2 * (step - 3) + 2 : L)>([&](auto r_) DCSCN_INL { convert_in(r_, li, lchunk); });
+                    static_for<2 * (step - 3), (2 * (step - 3) + 2 < L ? 2 * (step - 3) + 2 : L)>([&](auto r_) DCSCN_INL { convert_in(r_, li_all_in, li_ok, lchunk); });
             });
             if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
             c3p_barrier();                                    // every wave is past its last read of this chunk's image
@@ -292,15 +324,16 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
         if (octs) {
             int l = lane;
             asm volatile("" : "+v"(l));
-            for (int step = 0; step < n_tail; ++step) {
-                if (step == 1 || step == 2) c3p_wait_vm<F + L>(); else c3p_wait_vm<F>();
+            auto tail_step = [&](int step, auto first_c) DCSCN_INL {
+                constexpr bool FIRST = decltype(first_c)::value;             // step 0, peeled: the image loads must not sit under a condition
+                if (FIRST) c3p_wait_vm<F>(); else if (step == 1 || step == 2) c3p_wait_vm<F + L>(); else c3p_wait_vm<F>();
                 c3p_barrier();
                 {
                     const int k = step + 2 - n_tail;          // >= 0: step k of the next item (packed taps 0 and 3)
                     const char* src = k < 0 ? cur.f_base + (size_t)(n_main * 9 + step + 2) * G::F_TAP_BYTES : nxt.f_base + (size_t)(3 * k) * G::F_TAP_BYTES;
                     dma_f(src, s2);
                 }
-                if (step == 0) load_in(nxt, 0);
+                if constexpr (FIRST) load_in(nxt.a_base, nxt.ok_mask, 0);
                 const int pair = 4 * step + (l >> 4);
                 int tap = octs == 1 ? pair : octs == 2 ? pair >> 1 : (pair * 11) >> 5;      // pair / octs for pair < 36
                 const int oct = pair - tap * octs;
@@ -317,18 +350,22 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
                 const char* fs = smem + a_lane + s0;
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
                     constexpr int n = decltype(n_)::value;
-                    const h8 wh = *reinterpret_cast<const h8*>(fs + (2 * n) * 1024);
-                    const h8 wl = *reinterpret_cast<const h8*>(fs + (2 * n + 1) * 1024);
-                    static_for<0, 4>([&](auto m_) DCSCN_INL {
-                        constexpr int m = decltype(m_)::value;
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[m], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[m], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[m], acc[m][n], 0, 0, 0);
-                    });
+                    if (n < NT - 1 || wide) {
+                        const h8 wh = *reinterpret_cast<const h8*>(fs + (2 * n) * 1024);
+                        const h8 wl = *reinterpret_cast<const h8*>(fs + (2 * n + 1) * 1024);
+                        static_for<0, 4>([&](auto m_) DCSCN_INL {
+                            constexpr int m = decltype(m_)::value;
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[m], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[m], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[m], acc[m][n], 0, 0, 0);
+                        });
+                    }
                 });
                 const int t = s0; s0 = s1; s1 = s2; s2 = t;   // the ring moves on by one slot per step
-            }
-            static_for<0, L>([&](auto r_) DCSCN_INL { convert_in(r_, nxt, 0); });
+            };
+            tail_step(0, std::true_type{});
+            for (int step = 1; step < n_tail; ++step) tail_step(step, std::false_type{});
+            static_for<0, L>([&](auto r_) DCSCN_INL { convert_in(r_, nxt.all_in, nxt.ok_mask, 0); });
             if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
             c3p_barrier();
             store_in();
@@ -344,11 +381,15 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
         const float zero = opaque_zero();
         float chk = 0.0f;
         const bool fast = fastable && cur.full;
+        int le = lane;
+        asm volatile("" : "+v"(le));                           // the epilogue's lane arithmetic stays in the epilogue
+        const int lje = le & 15, lke = le >> 4;
         if (fast) {
             auto finish = [&](auto act_c) DCSCN_INL {
                 constexpr int ACT_C = decltype(act_c)::value;
                 static_for<0, NTV>([&](auto n_) DCSCN_INL {
                     constexpr int n = decltype(n_)::value;
+                    if (!(n < NT - 1 || wide)) return;
                     const int c0 = cb16 + n * 16;                                    // uniform
                     const bool first = c0 < a.split;
                     float* optr = first ? a.out0.ptr : a.out1.ptr;
@@ -357,12 +398,12 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
                     const int owidth = first ? a.out0.width : a.out1.width;
                     const int cc0 = first ? c0 : c0 - a.split;
                     char* base = reinterpret_cast<char*>(optr + ((size_t)(cur.img * H + cur.y0) * W + cur.x0) * ostride + ooff + cc0);
-                    const unsigned voff = (unsigned)(((4 * wave * W + lj) * ostride + 4 * lk) * 4);
+                    const unsigned voff = (unsigned)(((4 * wave * W + lje) * ostride + 4 * lke) * 4);
                     const unsigned rowb = (unsigned)(W * ostride * 4);
-                    const bool chan_ok = cc0 + 4 * lk < owidth;
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + ba + (n * 4 + lk) * 16);
+                    const bool chan_ok = cc0 + 4 * lke < owidth;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + ba + (n * 4 + lke) * 16);
                     f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if constexpr (ACT_C == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(smem + ba + NT * 64 + (n * 4 + lk) * 16);
+                    if constexpr (ACT_C == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(smem + ba + NT * 64 + (n * 4 + lke) * 16);
                     static_for<0, 4>([&](auto m_) DCSCN_INL {
                         constexpr int m = decltype(m_)::value;
                         f32x4 v = acc[m][n] * inv + bv;
@@ -381,17 +422,18 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
             else finish(std::integral_constant<int, ACT_NONE>{});
         } else {
             // general path (image edges, depth_to_space, residual, other activators): conv3_h's epilogue
-            const int cbase = ntile * NT * 16 + 4 * lk;
-            const int obase = cb16 + 4 * lk;
+            const int cbase = ntile * NT * 16 + 4 * lke;
+            const int obase = cb16 + 4 * lke;
             const int act = a.act, ps = a.ps, orow = W * ps;
-            const int gx = cur.x0 + lj;
+            const int gx = cur.x0 + lje;
             static_for<0, NTV>([&](auto n_) DCSCN_INL {
                 constexpr int n = decltype(n_)::value;
                 (void)cbase;
+                if (!(n < NT - 1 || wide)) return;
                 const int c = obase + n * 16;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + ba + (n * 4 + lk) * 16);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + ba + (n * 4 + lke) * 16);
                 f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (act == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(smem + ba + NT * 64 + (n * 4 + lk) * 16);
+                if (act == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(smem + ba + NT * 64 + (n * 4 + lke) * 16);
                 const bool first = c < a.split;
                 float* optr = first ? a.out0.ptr : a.out1.ptr;
                 const int ostride = first ? a.out0.stride : a.out1.stride;
@@ -429,11 +471,10 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
     };
 
     while (true) {
-        if (cur.ntile < a.n_full) run_item(std::integral_constant<int, NT>{});                 // block uniform
-        else if constexpr (NT >= 2) run_item(std::integral_constant<int, NT - 1>{});
-        cur = nxt;
-        if (!cur.valid) break;
-        decode(nn_id, nxt);
+        run_item();
+        if (!nxt.valid) break;
+        decode(nxt.id, cur, std::true_type{});
+        decode(nn_id, nxt, std::false_type{});
         parity ^= 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may land after the workgroup has given its LDS back

@@ -18,7 +18,9 @@
 #include "../dcscn-super-resolution_amd/csrc/split16_pack.hpp"
 #ifdef H16_CONV3
 #include "../dcscn-super-resolution_amd/csrc/conv3_h.hpp"
+#ifdef H16_HP
 #include "../dcscn-super-resolution_amd/csrc/conv3_hp.hpp"
+#endif
 #endif
 
 using namespace dcscn;
