@@ -1,0 +1,494 @@
+// conv3_h8: conv3_h's arithmetic (3x3 SAME conv + bias + activator, tf.nn.conv2d of helper/tf_graph.py:104-153, direct implicit GEMM on
+// v_mfma_f32_16x16x32_f16 with f16 (hi, lo) operands, three products per MAC: split16.hpp) with the workgroup rebuilt around what the
+// r04 probes measured (profiles/r04_conv3_h_probe.txt, r04_conv3_hp_probe.txt):
+//
+//   * a conv3_h wave needs ~2300 cycles per tap when it has its SIMD to itself -- 1152 of MFMAs and as much again of everything
+//     around them (barrier, filter DMA issue, LDS reads it has to wait for, staging of the next image) -- and two independent
+//     workgroups per CU hide only a quarter of that from each other: their non-MFMA phases are not forced apart;
+//   * every pixel tile's input is fetched, split into (hi, lo) and written to LDS once per channel GROUP (2.5x the algorithmic reads).
+//
+// Here ONE workgroup of 8 waves per CU owns a pixel tile for ALL its output channels: waves 0-3 (half 0) take one channel group,
+// waves 4-7 (half 1) the other (or the other half of the tiles of a single group), wave w and w + 4 share a SIMD, and the two halves
+// run in PING-PONG between workgroup barriers: while one half issues nothing but MFMAs (and the LDS reads feeding them) for its tap,
+// the other does everything else for ITS next tap -- waits for its filter DMA, issues the DMA two taps ahead, stages a slice of the
+// next image, and reads the first fragments of its tap into registers -- so that the matrix pipe of every SIMD goes from one wave
+// straight to the other at each barrier.
+//
+//   half 0:  LOAD(0) | COMPUTE(0) | LOAD(1) | COMPUTE(1) | ...
+//   half 1:          | LOAD(0)    | COMPUTE(0) | LOAD(1) | COMPUTE(1) | ...           ( | = s_barrier )
+//
+// * input image: ONE (hi, lo) image per 32-channel chunk for both halves, double buffered (2 x 41.5 KB): the 2592 (pixel, channel quad)
+//   items of chunk c + 1 are loaded at step 0 of chunk c by all 512 threads (6 loads each), split one round per step at steps 3..8 and
+//   written straight into the other buffer -- no chunk-boundary barrier, no second fetch for the second channel group.
+// * filters: a ring of three tap slots per half, filled by LDS-DMA two taps ahead; a tap's pieces are waited for ONE tap early (the
+//   wait is in the load phase and costs nothing), so the first fragments of a tap can be read before the barrier that starts its
+//   compute phase.
+// * the workgroup is persistent (one per CU, items dealt statically: equal work, no competition inside a CU): the next item's first
+//   image and first taps are in flight during the last taps of the current one, the epilogue of a half (lean path as conv3_hp's) runs
+//   in its first load phase of the next item.
+// * LDS: 2 x 41.5 + 2 x 3 x NT x 2 KB + bias = 156 KB at NT = 6.  VGPRs: 96 accumulators + 32 B + 16 A (double buffered) + 24 staged.
+//
+// vmcnt bookkeeping: per load phase F DMA instructions, then (step 0 only) 6 image loads; the wait at the head of a load phase needs
+// the pieces issued in the PREVIOUS load phase, so the count is the number of image loads issued behind them (6 after a step 0, else
+// 0); epilogue stores and anything else issued in between only make a wait longer than needed, never shorter.
+#pragma once
+#include "conv3_hp.hpp"
+
+namespace dcscn {
+
+template <int NT>
+struct C3EGeom {
+    static constexpr int THREADS = 512;
+    static constexpr int KC = 32, TH = 16, TW = 16, HT = 18, HP = HT * HT;
+    static constexpr int PIX_BYTES = 128, ROW_BYTES = HT * PIX_BYTES, IN_BYTES = HP * PIX_BYTES;   // 41472
+    static constexpr int IN_ITEMS = HP * 8;
+    static constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;                            // 6 (the last one: 32 items)
+    static constexpr int F_TAP_BYTES = NT * 2048;                 // one tap of one half: [n][hi | lo][64 lanes][16 bytes]
+    static constexpr int F_ROUNDS = (2 * NT + 3) / 4;             // DMA instructions per wave and tap
+    static constexpr int IMG = 0;                                 // two image buffers
+    static constexpr int F_BASE = 2 * IN_BYTES;                   // [half][slot]
+    static constexpr int BA_BASE = F_BASE + 2 * 3 * F_TAP_BYTES;  // [parity][half][bias | slopes]: NT * 128 bytes each
+    static constexpr int LDS_BYTES = BA_BASE + 4 * NT * 128;
+};
+
+// DBG (tuner only) 1: per wave through a.srctab: [0] entry, [1] exit, [2] items, [3] sum of load phases, [4] sum of compute phases,
+// [5] sum of the waits at the barrier ending a load phase, [6] same for compute phases, [7] sum of epilogues
+#ifndef C3E_PFD
+#define C3E_PFD 2          // A fragments are read this many channel tiles ahead of their MFMAs (the first PFD tiles in the load phase)
+#endif
+// NT = channel tiles of half 0, C1 = of half 1 (NT or NT - 1; 0 for a one-tile layer): launch constants -- the host instantiates the
+// pair a layer needs, every loop over tiles is straight-line code (a branch around a tile makes the compiler wait for ALL outstanding
+// LDS reads in front of every tile, and merging code variants cost 60 VGPRs in copies of the accumulators).
+template <int NT, int C1, int DBG = 0>
+__global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
+    static_assert(C1 == NT || C1 == NT - 1, "half 1 takes as many tiles as half 0 or one fewer");
+    constexpr int PFD = C3E_PFD < NT ? C3E_PFD : (NT > 1 ? NT - 1 : 1), NB = PFD + 1;
+    using G = C3EGeom<NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem_c3e[];
+    char* const smem = smem_c3e;
+    constexpr int F = G::F_ROUNDS, L = G::IN_ROUNDS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, w4 = wave & 3;
+    const int H = a.H, W = a.W;
+    const int n_groups = a.n_groups, ntp = a.nt_pack;
+    const int n_pairs = (n_groups + 1) >> 1;
+    const int n_units = a.N * a.tiles_y * a.tiles_x * n_pairs;
+    const int n_chunks = a.n_chunks;
+    const int octs = a.tail_octs;
+    const int n_main = octs ? n_chunks - 1 : n_chunks;
+    const int n_tail = (9 * octs + 3) >> 2;
+    const int t_total = n_main * 9 + n_tail;                   // taps (MFMA steps) of an item
+    const bool fastable = a.ps == 1 && a.res == nullptr && (a.act == ACT_ALPHA || a.act == ACT_NONE);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned f_off = (unsigned)(lane * 16);
+    const int cq = tid & 7;
+    const int tap_stride = ntp * 2048;                         // bytes between taps of a group's filter image
+    long long pr_t0 = 0, pr_load = 0, pr_comp = 0, pr_bl = 0, pr_bc = 0, pr_epi = 0, pr_a = 0, pr_b = 0;
+    int pr_items = 0;
+    if constexpr (DBG == 1) pr_t0 = __builtin_readcyclecounter();
+
+    // ---- what this half does of an item: channel group g, its tiles [o, o + cnt) ----
+    struct Unit {
+        int valid, tile_id, img, y0, x0, g, o;
+        bool all_in, full;
+        const char* a_base;
+        const char* f_base;
+        unsigned ok_mask;
+    };
+    auto decode = [&](int id, Unit& u) DCSCN_INL {
+        u.valid = id < n_units;
+        const int idc = u.valid ? id : 0;
+        const int tile_id = idc / n_pairs, p = idc - tile_id * n_pairs;
+        const int g0 = 2 * p;
+        if (g0 + 1 < n_groups) {
+            u.g = g0 + half; u.o = 0;
+        } else {                                               // one group left: its tiles are split between the halves
+            u.g = g0; u.o = half ? NT : 0;                      // half 0 takes the group's first NT tiles
+        }
+        int bid = tile_id;
+        const int tx = bid % a.tiles_x;
+        bid /= a.tiles_x;
+        const int ty = bid % a.tiles_y;
+        u.tile_id = tile_id;
+        u.img = bid / a.tiles_y;
+        u.y0 = ty * G::TH; u.x0 = tx * G::TW;
+        u.all_in = u.y0 >= 1 && u.x0 >= 1 && u.y0 + G::TH + 1 <= H && u.x0 + G::TW + 1 <= W;
+        u.full = u.y0 + G::TH <= H && u.x0 + G::TW <= W;
+        u.a_base = reinterpret_cast<const char*>(a.in + (size_t)u.img * H * W * a.in_stride + a.in_off + ((ptrdiff_t)(u.y0 - 1) * W + (u.x0 - 1)) * a.in_stride);
+        u.f_base = reinterpret_cast<const char*>(a.wpack16) + (size_t)u.g * n_chunks * 9 * tap_stride + (size_t)u.o * 2048;
+        unsigned m = 0;
+        int hp0 = tid >> 3;
+        asm volatile("" : "+v"(hp0));
+        int hrow = hp0 / G::HT, hcol = hp0 - G::HT * hrow;     // item r: halo pixel hp0 + 64 r = 3 rows and 10 columns further per round
+        static_for<0, L>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            const int gy = u.y0 - 1 + hrow, gx = u.x0 - 1 + hcol;
+            const bool ok = r * 64 + hp0 < G::HP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            m |= ok ? (1u << r) : 0u;
+            hcol += 64 - 3 * G::HT; hrow += 3;
+            if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
+        });
+        u.ok_mask = m;
+    };
+
+    // ---- image staging: item = r * 512 + tid = (halo pixel r * 64 + (tid >> 3), channel quad tid & 7) ----
+    f32x4 gin[L];
+    auto load_in = [&](const char* base, unsigned mask, int chunk) DCSCN_INL {
+        const int c0 = chunk * G::KC + cq * 4;
+        const unsigned coff = (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4);
+        int hp0 = tid >> 3;
+        asm volatile("" : "+v"(hp0));
+        int hrow = hp0 / G::HT, hcol = hp0 - G::HT * hrow;
+        const int stride4 = a.in_stride * 4;
+        static_for<0, L>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            const int pix = ((mask >> r) & 1u) ? hrow * W + hcol : W + 1;
+            gin[r] = *reinterpret_cast<const f32x4*>(base + (size_t)((unsigned)(pix * stride4) + coff));
+            hcol += 64 - 3 * G::HT; hrow += 3;
+            if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
+        });
+    };
+    const float m1 = opaque_minus_one();
+    // round r of the image in flight: zero what is padding, split, write to image buffer `buf`
+    auto convert_store = [&](auto r_, bool all_in, unsigned mask, int chunk, int buf) DCSCN_INL {
+        constexpr int r = decltype(r_)::value;
+        f32x4 x = gin[r];
+        const bool whole = all_in && (chunk + 1) * G::KC <= a.cin_phys;
+        if (!whole) {
+            const bool ok = chunk * G::KC + cq * 4 < a.cin_phys && ((mask >> r) & 1u);
+            x.x = ok ? x.x : 0.0f; x.y = ok ? x.y : 0.0f; x.z = ok ? x.z : 0.0f; x.w = ok ? x.w : 0.0f;
+        }
+        h4 hi, lo;
+        split4(x, m1, hi, lo);
+        const u32x2 hu = __builtin_bit_cast(u32x2, hi), lu = __builtin_bit_cast(u32x2, lo);
+        int hp0 = tid >> 3;
+        asm volatile("" : "+v"(hp0));
+        const int hp = r * 64 + hp0;
+        const int hcol = hp % G::HT;
+        const int kq = cq >> 1;
+        const int unit = (((kq + ((hcol >> 1) & 3)) & 3) << 1) | (kq & 1);
+        const int off = buf * G::IN_BYTES + hp * G::PIX_BYTES + unit * 16 + (cq & 1) * 8;
+        if (r < L - 1 || hp < G::HP) {
+            *reinterpret_cast<u32x2*>(smem + off) = hu;
+            *reinterpret_cast<u32x2*>(smem + (off ^ 16)) = lu;
+        }
+    };
+    // one tap of this half's filters -> ring slot
+    auto dma_f = [&](const char* src, int slot, int cnt) DCSCN_INL {
+        const int pieces = cnt > 0 ? 2 * cnt : 1;
+        static_for<0, F>([&](auto r_) DCSCN_INL {
+            constexpr int r = decltype(r_)::value;
+            const int piece = (w4 + 4 * r) % pieces;
+            glds16(src + piece * 1024, f_off, lds0 + (unsigned)(G::F_BASE + (half * 3 + slot) * G::F_TAP_BYTES) + (unsigned)piece * 1024u);
+        });
+    };
+    // address of tap `tt` of unit u's filter image (tt may run past the item: then it is a tap of the next unit)
+    auto tap_src = [&](const Unit& u, const Unit& un, int tt) DCSCN_INL -> const char* {
+        const Unit& w = tt < t_total ? u : un;
+        const int t = tt < t_total ? tt : tt - t_total;
+        int idx;
+        if (t < n_main * 9) { const int c = t / 9, s = t - 9 * c; idx = c * 9 + (s % 3) * 3 + s / 3; }
+        else idx = t;                                          // the packed tail's slots are in step order
+        return w.f_base + (size_t)idx * tap_stride;
+    };
+
+    auto run = [&](auto cnt_c) DCSCN_INL {
+    constexpr int CNT = decltype(cnt_c)::value;                // channel tiles of THIS half
+    // ---- first item ----
+    Unit cur, nxt;
+    int id = blockIdx.x;
+    decode(id, cur);
+    if (!cur.valid) return;
+    decode(id + (int)gridDim.x, nxt);
+    int ibuf = 0;                                              // image buffer of the chunk being computed
+    int tslot = 0;                                             // ring slot of the tap being computed (both halves count alike)
+    dma_f(tap_src(cur, nxt, 0), 0, CNT);
+    dma_f(tap_src(cur, nxt, 1), 1, CNT);
+    load_in(cur.a_base, cur.ok_mask, 0);
+    static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, cur.all_in, cur.ok_mask, 0, 0); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    c3p_barrier();
+    if (half == 1) c3p_barrier();                              // half 1 runs one phase behind half 0
+
+    f32x4 acc[4][NT];
+    h8 xh[4], xl[4], wa[NB], wb[NB];                           // B rows (hi, lo), A fragments (wl, wh) in a ring of PFD + 1 tiles
+    bool pending = false;                                      // an epilogue is owed (previous item)
+    int parity = 0;
+    // epilogue state of the previous item (its accumulators are still in acc until the first compute phase of the next item)
+    int e_tile = 0, e_img = 0, e_y0 = 0, e_x0 = 0, e_g = 0, e_o = 0;
+    bool e_full = false;
+
+    auto epilogue = [&]() DCSCN_INL {
+        if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
+        const int ba = G::BA_BASE + ((parity ^ 1) * 2 + half) * NT * 128;
+        const int cb16 = e_g * ntp * 16 - 16 * (e_g > a.n_full ? e_g - a.n_full : 0) + e_o * 16;   // conv channel of the half's first tile
+        const float inv = a.inv_scale;
+        const float zero = opaque_zero();
+        float chk = 0.0f;
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int lje = le & 15, lke = le >> 4;
+        if (fastable && e_full) {
+            auto finish = [&](auto act_c) DCSCN_INL {
+                constexpr int ACT_C = decltype(act_c)::value;
+                static_for<0, CNT>([&](auto n_) DCSCN_INL {
+                    constexpr int n = decltype(n_)::value;
+                    const int c0 = cb16 + n * 16;
+                    const bool first = c0 < a.split;
+                    float* optr = first ? a.out0.ptr : a.out1.ptr;
+                    const int ostride = first ? a.out0.stride : a.out1.stride;
+                    const int ooff = first ? a.out0.off : a.out1.off;
+                    const int owidth = first ? a.out0.width : a.out1.width;
+                    const int cc0 = first ? c0 : c0 - a.split;
+                    char* base = reinterpret_cast<char*>(optr + ((size_t)(e_img * H + e_y0) * W + e_x0) * ostride + ooff + cc0);
+                    const unsigned voff = (unsigned)(((4 * w4 * W + lje) * ostride + 4 * lke) * 4);
+                    const unsigned rowb = (unsigned)(W * ostride * 4);
+                    const bool chan_ok = cc0 + 4 * lke < owidth;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + ba + (n * 4 + lke) * 16);
+                    f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if constexpr (ACT_C == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(smem + ba + NT * 64 + (n * 4 + lke) * 16);
+                    static_for<0, 4>([&](auto m_) DCSCN_INL {
+                        constexpr int m = decltype(m_)::value;
+                        f32x4 v = acc[m][n] * inv + bv;
+                        if constexpr (ACT_C == ACT_ALPHA) {
+                            v.x = v.x > 0.0f ? v.x : av.x * v.x;
+                            v.y = v.y > 0.0f ? v.y : av.y * v.y;
+                            v.z = v.z > 0.0f ? v.z : av.z * v.z;
+                            v.w = v.w > 0.0f ? v.w : av.w * v.w;
+                        }
+                        if (chan_ok) chk = nonfinite_acc(chk, acc[m][n], zero);
+                        if (chan_ok) *reinterpret_cast<f32x4*>(base + (size_t)(voff + m * rowb)) = v;
+                    });
+                });
+            };
+            if (a.act == ACT_ALPHA) finish(std::integral_constant<int, ACT_ALPHA>{});
+            else finish(std::integral_constant<int, ACT_NONE>{});
+        } else {
+            const int obase = cb16 + 4 * lke;
+            const int act = a.act, ps = a.ps, orow = W * ps;
+            const int gx = e_x0 + lje;
+            static_for<0, CNT>([&](auto n_) DCSCN_INL {
+                constexpr int n = decltype(n_)::value;
+                const int c = obase + n * 16;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + ba + (n * 4 + lke) * 16);
+                f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (act == ACT_ALPHA) av = *reinterpret_cast<const f32x4*>(smem + ba + NT * 64 + (n * 4 + lke) * 16);
+                const bool first = c < a.split;
+                float* optr = first ? a.out0.ptr : a.out1.ptr;
+                const int ostride = first ? a.out0.stride : a.out1.stride;
+                const int ooff = first ? a.out0.off : a.out1.off;
+                const int owidth = first ? a.out0.width : a.out1.width;
+                const int cc = first ? c : c - a.split;
+                int ch = cc, ay = 0, bx = 0;
+                if (ps != 1) {
+                    const int sub = cc / a.ps_c;
+                    ch = cc - sub * a.ps_c;
+                    ay = sub / ps;
+                    bx = sub - ay * ps;
+                }
+                const bool live = gx < W && cc < owidth;
+                static_for<0, 4>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    const int gy = e_y0 + 4 * w4 + m;
+                    f32x4 v = acc[m][n] * inv + bv;
+                    v.x = activate1(v.x, av.x, act);
+                    v.y = activate1(v.y, av.y, act);
+                    v.z = activate1(v.z, av.z, act);
+                    v.w = activate1(v.w, av.w, act);
+                    if (live && gy < H) {
+                        chk = nonfinite_acc(chk, acc[m][n], zero);
+                        const size_t pix = (size_t)((e_img * H + gy) * ps + ay) * orow + (size_t)(gx * ps + bx);
+                        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + pix * a.res_stride + ch);
+                        *reinterpret_cast<f32x4*>(optr + pix * ostride + ooff + ch) = v;
+                    }
+                });
+            });
+        }
+        if (chk != chk && a.redo) a.redo[e_tile] = 1;
+        pending = false;
+        if constexpr (DBG == 1) { pr_epi += __builtin_readcyclecounter() - pr_a; ++pr_items; }
+    };
+    auto phase_barrier = [&](long long& acc_wait) DCSCN_INL {
+        if constexpr (DBG == 1) pr_b = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);                     // MFMAs have no memory effect: without this the scheduler moves some across the barrier
+        c3p_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DBG == 1) acc_wait += __builtin_readcyclecounter() - pr_b;
+    };
+
+    while (true) {
+        // bias / slopes of this item's tiles (the previous item's epilogue reads the other parity)
+        {
+            const int ba = G::BA_BASE + (parity * 2 + half) * NT * 128;
+            const int t4 = tid & 255;
+            const int boff = cur.g * ntp * 16 + cur.o * 16;
+            if (t4 < NT * 4) {
+                if (t4 < CNT * 4) *reinterpret_cast<f32x4*>(smem + ba + t4 * 16) = reinterpret_cast<const f32x4*>(a.bias + boff)[t4];
+            } else if (t4 >= 64 && t4 < 64 + NT * 4 && a.act == ACT_ALPHA) {
+                if (t4 - 64 < CNT * 4) *reinterpret_cast<f32x4*>(smem + ba + NT * 64 + (t4 - 64) * 16) = reinterpret_cast<const f32x4*>(a.alpha + boff)[t4 - 64];
+            }
+        }
+        int b_hi = 0;
+        const int a_lane = lane * 16;
+        int tt = 0;                                            // tap index inside the item
+        for (int chunk = 0; chunk < n_main; ++chunk) {
+            const bool last_main = chunk + 1 == n_main;
+            const bool ends = last_main && octs == 0;
+            const char* li_base = ends ? nxt.a_base : cur.a_base;
+            const unsigned li_ok = ends ? nxt.ok_mask : cur.ok_mask;
+            const bool li_all_in = ends ? nxt.all_in : cur.all_in;
+            const int lchunk = ends ? 0 : chunk + 1;
+            const int img_off = ibuf * G::IN_BYTES;
+            static_for<0, 9>([&](auto s_) DCSCN_INL {
+                constexpr int step = decltype(s_)::value;
+                constexpr int kx = step / 3, ky = step % 3;
+                // ================= LOAD phase of this tap =================
+                if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
+                if constexpr (step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>();        // the pieces issued in the previous load phase
+                {   // the tap two steps ahead: of this chunk, of the next one, of the packed tail, or of the next item
+                    constexpr int step2 = (step + 2) % 9;
+                    constexpr int ptap2 = (step2 % 3) * 3 + step2 / 3;
+                    const char* src;
+                    if constexpr (step + 2 < 9) src = cur.f_base + (size_t)(chunk * 9 + ptap2) * tap_stride;
+                    else src = !last_main ? cur.f_base + (size_t)((chunk + 1) * 9 + ptap2) * tap_stride
+                             : octs      ? cur.f_base + (size_t)(n_main * 9 + step2) * tap_stride
+                                         : nxt.f_base + (size_t)ptap2 * tap_stride;
+                    dma_f(src, (tslot + 2) % 3, CNT);
+                }
+                if constexpr (step == 0) load_in(li_base, li_ok, lchunk);
+                if constexpr (step >= 3) convert_store(std::integral_constant<int, step - 3>{}, li_all_in, li_ok, lchunk, ibuf ^ 1);
+                if constexpr (step == 0) { if (chunk == 0 && pending) epilogue(); }
+                // first fragments of this tap: the new B row(s) and the A fragments of tile 0
+                if constexpr (ky == 0) {
+                    int l = lane;
+                    asm volatile("" : "+v"(l));
+                    const int hx = (l & 15) + kx;
+                    b_hi = img_off + (4 * w4 * G::HT + hx) * G::PIX_BYTES + c3h_unit(hx, l >> 4, 0) * 16;
+                }
+                static_for<(ky == 0 ? 0 : 3), 4>([&](auto m_) DCSCN_INL {
+                    constexpr int row = ky + decltype(m_)::value;
+                    xh[row & 3] = *reinterpret_cast<const h8*>(smem + b_hi + row * G::ROW_BYTES);
+                    xl[row & 3] = *reinterpret_cast<const h8*>(smem + (b_hi ^ 16) + row * G::ROW_BYTES);
+                });
+                const char* fs = smem + G::F_BASE + (half * 3 + tslot) * G::F_TAP_BYTES + a_lane;
+                static_for<0, PFD>([&](auto p_) DCSCN_INL {
+                    constexpr int p = decltype(p_)::value;
+                    wb[p] = *reinterpret_cast<const h8*>(fs + (2 * p) * 1024);       // (tiles past the half's last: stale bytes of its own slot, never used)
+                    wa[p] = *reinterpret_cast<const h8*>(fs + (2 * p + 1) * 1024);
+                });
+                if constexpr (DBG == 1) pr_load += __builtin_readcyclecounter() - pr_a;
+                phase_barrier(pr_bl);
+                // ================= COMPUTE phase =================
+                if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
+                if constexpr (step == 0) {
+                    if (chunk == 0)
+                        static_for<0, 4>([&](auto m_) DCSCN_INL {
+                            static_for<0, NT>([&](auto n_) DCSCN_INL { acc[decltype(m_)::value][decltype(n_)::value] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; });
+                        });
+                }
+                auto mfmas = [&](auto cnt_c) DCSCN_INL {
+                    constexpr int CNT = decltype(cnt_c)::value;
+                    static_for<0, CNT>([&](auto n_) DCSCN_INL {
+                        constexpr int n = decltype(n_)::value;
+                        if constexpr (n + PFD < CNT) {
+                            wb[(n + PFD) % NB] = *reinterpret_cast<const h8*>(fs + (2 * (n + PFD)) * 1024);
+                            wa[(n + PFD) % NB] = *reinterpret_cast<const h8*>(fs + (2 * (n + PFD) + 1) * 1024);
+                        }
+                        static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[n % NB], xh[(ky + m) & 3], acc[m][n], 0, 0, 0); });
+                        static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[n % NB], xl[(ky + m) & 3], acc[m][n], 0, 0, 0); });
+                        static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[n % NB], xh[(ky + m) & 3], acc[m][n], 0, 0, 0); });
+                        __builtin_amdgcn_sched_barrier(0);     // a tile's reads and MFMAs stay where they are (hoisted, the reads of all tiles cost 40 more registers)
+                    });
+                };
+                mfmas(std::integral_constant<int, CNT>{});
+                if constexpr (DBG == 1) pr_comp += __builtin_readcyclecounter() - pr_a;
+                phase_barrier(pr_bc);
+                ++tt;
+                tslot = tslot == 2 ? 0 : tslot + 1;
+            });
+            ibuf ^= 1;
+        }
+        // ---- packed tail: (tap, octet) pairs four to an instruction; the next item's first image is staged here ----
+        if (octs) {
+            const int img_off = ibuf * G::IN_BYTES;
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            auto tail_step = [&](int step, auto first_c) DCSCN_INL {
+                constexpr bool FIRST = decltype(first_c)::value;
+                if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
+                if (!FIRST && step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>();
+                dma_f(tap_src(cur, nxt, tt + 2), (tslot + 2) % 3, CNT);
+                if constexpr (FIRST) load_in(nxt.a_base, nxt.ok_mask, 0);
+                if (!FIRST && step == 2) static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, nxt.all_in, nxt.ok_mask, 0, ibuf ^ 1); });
+                const int pair = 4 * step + (l >> 4);
+                int tap = octs == 1 ? pair : octs == 2 ? pair >> 1 : (pair * 11) >> 5;
+                const int oct = pair - tap * octs;
+                tap = tap < 8 ? tap : 8;
+                const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+                const int hx = (l & 15) + kx;
+                const int b = img_off + ((4 * w4 + ky) * G::HT + hx) * G::PIX_BYTES + c3h_unit(hx, oct, 0) * 16;
+                static_for<0, 4>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    xh[m] = *reinterpret_cast<const h8*>(smem + b + m * G::ROW_BYTES);
+                    xl[m] = *reinterpret_cast<const h8*>(smem + (b ^ 16) + m * G::ROW_BYTES);
+                });
+                const char* fs = smem + G::F_BASE + (half * 3 + tslot) * G::F_TAP_BYTES + a_lane;
+                static_for<0, PFD>([&](auto p_) DCSCN_INL {
+                    constexpr int p = decltype(p_)::value;
+                    wb[p] = *reinterpret_cast<const h8*>(fs + (2 * p) * 1024);       // (tiles past the half's last: stale bytes of its own slot, never used)
+                    wa[p] = *reinterpret_cast<const h8*>(fs + (2 * p + 1) * 1024);
+                });
+                if constexpr (DBG == 1) pr_load += __builtin_readcyclecounter() - pr_a;
+                phase_barrier(pr_bl);
+                if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
+                auto mfmas = [&](auto cnt_c) DCSCN_INL {
+                    constexpr int CNT = decltype(cnt_c)::value;
+                    static_for<0, CNT>([&](auto n_) DCSCN_INL {
+                        constexpr int n = decltype(n_)::value;
+                        if constexpr (n + PFD < CNT) {
+                            wb[(n + PFD) % NB] = *reinterpret_cast<const h8*>(fs + (2 * (n + PFD)) * 1024);
+                            wa[(n + PFD) % NB] = *reinterpret_cast<const h8*>(fs + (2 * (n + PFD) + 1) * 1024);
+                        }
+                        static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[n % NB], xh[m], acc[m][n], 0, 0, 0); });
+                        static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[n % NB], xl[m], acc[m][n], 0, 0, 0); });
+                        static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[n % NB], xh[m], acc[m][n], 0, 0, 0); });
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                };
+                mfmas(std::integral_constant<int, CNT>{});
+                if constexpr (DBG == 1) pr_comp += __builtin_readcyclecounter() - pr_a;
+                phase_barrier(pr_bc);
+                ++tt;
+                tslot = tslot == 2 ? 0 : tslot + 1;
+            };
+            tail_step(0, std::true_type{});
+            for (int step = 1; step < n_tail; ++step) tail_step(step, std::false_type{});
+            ibuf ^= 1;
+        }
+        // ---- item done: its epilogue is run inside the first load phase of the next item (or below, for the last one) ----
+        pending = true;
+        e_tile = cur.tile_id; e_img = cur.img; e_y0 = cur.y0; e_x0 = cur.x0; e_g = cur.g; e_o = cur.o; e_full = cur.full;
+        parity ^= 1;
+        if (!nxt.valid) break;
+        id += (int)gridDim.x;
+        decode(id, cur);
+        decode(id + (int)gridDim.x, nxt);
+    }
+    epilogue();
+    if (half == 0) c3p_barrier();                              // pairs with half 1's extra barrier at the start
+    };
+    if (half == 0) run(std::integral_constant<int, NT>{});
+    else run(std::integral_constant<int, C1>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may land after the workgroup has given its LDS back
+    if constexpr (DBG == 1) {
+        if (lane == 0 && a.srctab) {
+            long long* pr = reinterpret_cast<long long*>(const_cast<void*>(a.srctab)) + ((size_t)blockIdx.x * 8 + wave) * 8;
+            pr[0] = pr_t0; pr[1] = __builtin_readcyclecounter(); pr[2] = pr_items; pr[3] = pr_load; pr[4] = pr_comp; pr[5] = pr_bl; pr[6] = pr_bc; pr[7] = pr_epi;
+        }
+    }
+}
+
+}  // namespace dcscn

@@ -31,8 +31,11 @@ def _model(tmp_path, key, **extra):
     return g, m
 
 
+@pytest.mark.parametrize("split16", ["1", "0"])
 @pytest.mark.parametrize("key", ["L7_x2", "L7_x3", "L7_x4", "L7_x4_DS", "L2_x2"])
-def test_set5_psnr_matches_oracle(tmp_path, key):
+def test_set5_psnr_matches_oracle(tmp_path, key, split16, monkeypatch):
+    """Real weights, real images, both kernel families (DCSCN_SPLIT16 = 1: f16 hi/lo x 3 products, the default; 0: pure f32)."""
+    monkeypatch.setenv("DCSCN_SPLIT16", split16)
     g, m = _model(tmp_path, key)
     psnrs = [m.do_for_evaluate(os.path.join(GOLDEN, "set5", f))[0] for f in g["files"]]
     m.close()
@@ -42,10 +45,12 @@ def test_set5_psnr_matches_oracle(tmp_path, key):
     assert abs(float(np.mean(psnrs)) - g["models"][key]["set5_mean"]) <= 1e-3
 
 
+@pytest.mark.parametrize("split16", ["1", "0"])
 @pytest.mark.parametrize("key", ["L7_x2", "L7_x3", "L7_x4"])
-def test_set14_psnr_matches_oracle(tmp_path, key):
+def test_set14_psnr_matches_oracle(tmp_path, key, split16, monkeypatch):
     """Set14 (README.md:60-62: 32.74 / 29.47 / 27.76 dB for these checkpoints), including the grayscale image that
     takes the monochrome branch of do_for_evaluate (DCSCN.py:688-696: uint8 'L'-mode resizes)."""
+    monkeypatch.setenv("DCSCN_SPLIT16", split16)
     g, m = _model(tmp_path, key)
     psnrs = [m.do_for_evaluate(os.path.join(GOLDEN, "set14", f))[0] for f in g["set14"]["files"]]
     m.close()

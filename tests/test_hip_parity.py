@@ -13,19 +13,25 @@ pytestmark = pytest.mark.gpu
 MAX_ABS_TOL = 1e-4
 
 
-def _engine(cfg, weights, winograd=None):
+# The two kernel families of the product: split16 (f16 hi/lo x 3 products on the f16 matrix pipe: conv3_h / conv_nin_h / conv5_h,
+# the library default) and pure f32 (conv_wino2 / conv_nin / conv_igemm: split16 = 0, also the fallback of every flagged tile).
+# with split16 the default the f32 family had lost most of its coverage; the tests below run both.
+SPLIT16 = [True, False]
+
+
+def _engine(cfg, weights, winograd=None, split16=None):
     from dcscn_amd import engine
     eng = engine.Engine(cfg, device=0)
-    eng.load_weights(weights, winograd=winograd)
+    eng.load_weights(weights, winograd=winograd, split16=split16)
     return eng
 
 
-def _check(oracle, name, overrides, n, h, w, seed=0, sub_batch_pixels=None, winograd=None):
+def _check(oracle, name, overrides, n, h, w, seed=0, sub_batch_pixels=None, winograd=None, split16=None):
     cfg = oracle.make_config(**overrides)
     weights = oracle.synthetic_weights(cfg, seed=seed)
     x, x2 = synthetic_batch(n, h, w, cfg["scale"], seed=seed + 1)
     ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
-    with _engine(cfg, weights, winograd) as eng:
+    with _engine(cfg, weights, winograd, split16) as eng:
         if sub_batch_pixels:
             eng.set_option("sub_batch_pixels", sub_batch_pixels)
         y = eng.forward(x, x2)
@@ -37,19 +43,22 @@ def _check(oracle, name, overrides, n, h, w, seed=0, sub_batch_pixels=None, wino
     assert err <= MAX_ABS_TOL, "%s: max-abs error %.3g > %.1g" % (name, err, MAX_ABS_TOL)
 
 
+@pytest.mark.parametrize("split16", SPLIT16)
 @pytest.mark.parametrize("winograd", [True, False])
 @pytest.mark.parametrize("name", sorted(CONFIGS))
-def test_config_48x48(oracle, name, winograd):
-    """Every BASELINE config (and every shipped-checkpoint topology) on 48x48 patches, with the 3x3
-    convs on the Winograd kernel (library default) and on the direct implicit-GEMM kernel."""
+def test_config_48x48(oracle, name, winograd, split16):
+    """Every BASELINE config (and every shipped-checkpoint topology) on 48x48 patches: 3x3 convs on conv3_h (split16, default),
+    on the f32 Winograd kernel (split16 off) and on the direct implicit-GEMM kernel (winograd off), wide 1x1 convs on
+    conv_nin_h / conv_nin."""
     n = 2 if "L12" in name or "L8" in name else 3
-    _check(oracle, name, CONFIGS[name], n, 48, 48, winograd=winograd)
+    _check(oracle, name, CONFIGS[name], n, 48, 48, winograd=winograd, split16=split16)
 
 
+@pytest.mark.parametrize("split16", SPLIT16)
 @pytest.mark.parametrize("fold", [True, False])
 @pytest.mark.parametrize("winograd", [True, False])
 @pytest.mark.parametrize("name", sorted(CONFIGS))
-def test_residual_branch_relative_error(oracle, name, winograd, fold):
+def test_residual_branch_relative_error(oracle, name, winograd, fold, split16):
     """The synthetic weights scale the last conv by 0.01, which would hide upstream errors behind the
     bicubic term.  Here the last conv is NOT scaled and x2 = 0, so y is the bare network branch; its
     error is bounded relative to its own magnitude (f32 accumulation over K <= 1764 terms) -- for EVERY
@@ -66,11 +75,11 @@ def test_residual_branch_relative_error(oracle, name, winograd, fold):
     ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
     from dcscn_amd import engine
     eng = engine.Engine(cfg, device=0)
-    eng.load_weights(weights, winograd=winograd, fold_tail=fold)
+    eng.load_weights(weights, winograd=winograd, fold_tail=fold, split16=split16)
     y = eng.forward(x, x2)
     eng.close()
     rel = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
-    print("%s winograd=%s fold=%s residual-branch relative error %.3g (max|y| %.3g)" % (name, winograd, fold, rel, np.max(np.abs(ref))))
+    print("%s winograd=%s fold=%s split16=%s residual-branch relative error %.3g (max|y| %.3g)" % (name, winograd, fold, split16, rel, np.max(np.abs(ref))))
     assert rel <= 5e-6
 
 
@@ -162,13 +171,14 @@ def test_split16_overflow_falls_back_to_f32(oracle):
     assert np.array_equal(y[0], y0[0])
 
 
+@pytest.mark.parametrize("split16", SPLIT16)
 @pytest.mark.parametrize("hw", [(1, 1), (5, 7), (16, 16), (17, 33), (31, 9), (50, 20)])
-def test_ragged_sizes(oracle, hw):
+def test_ragged_sizes(oracle, hw, split16):
     """Image sizes that are not multiples of the pixel tiles (odd sizes also cut Winograd's 2x2 output
-    tiles), down to a single pixel; channel counts that are not multiples of 4 or 16."""
-    _check(oracle, "L7_F32to8_x2", CONFIGS["L7_F32to8_x2"], 2, hw[0], hw[1])
-    _check(oracle, "odd-channels", dict(layers=4, filters=37, min_filters=13, nin_filters=21, nin_filters2=10), 1, hw[0], hw[1])
-    _check(oracle, "wide-odd", dict(layers=3, filters=70, min_filters=45, nin_filters=40, nin_filters2=33), 1, hw[0], hw[1])
+    tiles), down to a single pixel; channel counts that are not multiples of 4 or 16 -- on both kernel families."""
+    _check(oracle, "L7_F32to8_x2", CONFIGS["L7_F32to8_x2"], 2, hw[0], hw[1], split16=split16)
+    _check(oracle, "odd-channels", dict(layers=4, filters=37, min_filters=13, nin_filters=21, nin_filters2=10), 1, hw[0], hw[1], split16=split16)
+    _check(oracle, "wide-odd", dict(layers=3, filters=70, min_filters=45, nin_filters=40, nin_filters2=33), 1, hw[0], hw[1], split16=split16)
 
 
 def test_sub_batching_is_transparent(oracle):
@@ -231,17 +241,89 @@ def test_transcendental_activators(oracle, act):
     assert float(np.max(np.abs(y - ref))) <= 1e-3
 
 
+@pytest.mark.parametrize("split16", SPLIT16)
 @pytest.mark.parametrize("n_ens", [1, 2, 5, 8])
-def test_self_ensemble(oracle, n_ens):
+def test_self_ensemble(oracle, n_ens, split16):
     """do() with self_ensemble (DCSCN.py:559-573): batched on the device, float64 mean in reference order."""
     cfg = oracle.make_config(**CONFIGS["L7_F32to8_x2"])
     weights = oracle.synthetic_weights(cfg, seed=5)
     x, x2 = synthetic_batch(1, 18, 30, 2, seed=6)
     ref = oracle.do(cfg, weights, x[0], x2[0], self_ensemble=n_ens, dtype=np.float64)
-    with _engine(cfg, weights) as eng:
+    with _engine(cfg, weights, split16=split16) as eng:
         y = eng.forward_ensemble(x[0], x2[0], n_ens)
     assert y.dtype == np.float64 and y.shape == ref.shape
     assert float(np.max(np.abs(y - ref))) <= MAX_ABS_TOL
+
+
+@pytest.mark.parametrize("name", ["L8_F96to48_x2", "L12_F196to48_x2", "L7_F32to8_x2"])
+def test_small_magnitude_inputs_on_split16(oracle, name):
+    """Inputs in [0, 1] (--max_value=1 feeds the network image * 1/255: DCSCN.py:555-557): the split16 path splits activations
+    UNSCALED, so small values lean on f16 subnormals for their `lo` pieces (absolute floor ~3e-8 per element, split16.hpp).  Bare
+    network branch (last conv not attenuated, x2 = 0) against the float64 oracle at the same 5e-6 relative bar as on 0..255 data."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS[name])
+    weights = oracle.synthetic_weights(cfg, seed=7)
+    last = "R-CNN%d" % cfg["reconstruct_layers"]
+    weights[last + "/conv_W"] = weights[last + "/conv_W"] * 100.0
+    # the synthetic biases (~N(0, 0.1)) would dominate a [0, 1] input: scale them with the data so that the activations really are small
+    for k in list(weights):
+        if k.endswith("conv_B"):
+            weights[k] = weights[k] / 255.0
+    x, _ = synthetic_batch(2, 48, 48, 2, seed=8)
+    x = (x / 255.0).astype(np.float32)
+    x2 = np.zeros((2, 96, 96, 1), np.float32)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    rels = {}
+    for s16 in (True, False):
+        with engine.Engine(cfg, device=0) as eng:
+            eng.load_weights(weights, split16=s16)
+            y = eng.forward(x, x2)
+        rels[s16] = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
+    print("%s inputs in [0, 1]: residual-branch relative error split16 %.3g, f32 kernels %.3g (max|y| %.3g)" % (name, rels[True], rels[False], np.max(np.abs(ref))))
+    assert rels[True] <= 5e-6 and rels[False] <= 5e-6
+
+
+@pytest.mark.parametrize("split16", SPLIT16)
+@pytest.mark.parametrize("max_value", [1.0, 100.0])
+def test_do_with_max_value(oracle, tmp_path, max_value, split16, monkeypatch):
+    """SuperResolution.do() with --max_value != 255 (DCSCN.py:555-557, 581-584): image and bicubic image are multiplied by
+    max_value / 255 before the network and the output by 255 / max_value after it; self_ensemble 1 and 8."""
+    from dcscn_amd.model import SuperResolution
+    from test_host import _flags
+    monkeypatch.setenv("DCSCN_SPLIT16", "1" if split16 else "0")
+    over = dict(layers=4, filters=40, min_filters=24, nin_filters=32, nin_filters2=16)
+    cfg = oracle.make_config(**over)
+    weights = oracle.synthetic_weights(cfg, seed=11)
+    x, x2 = synthetic_batch(1, 30, 44, 2, seed=12)
+    for n_ens in (1, 8):
+        m = SuperResolution(_flags(max_value=max_value, self_ensemble=n_ens, checkpoint_dir=str(tmp_path / "models"), **over))
+        m.build_graph()
+        m.init_all_variables()
+        m.load_weights(weights)
+        y = m.do(x[0], x2[0])
+        m.close()
+        ref = oracle.do(cfg, weights, x[0], x2[0], self_ensemble=n_ens, max_value=max_value)
+        err = float(np.max(np.abs(np.asarray(y, np.float64) - ref)))
+        print("do() max_value=%g self_ensemble=%d split16=%s: max-abs %.3g" % (max_value, n_ens, split16, err))
+        assert y.shape == ref.shape and err <= MAX_ABS_TOL
+
+
+def test_debug_poison_changes_nothing(oracle):
+    """No kernel may depend on what LDS or the vector registers held before it: with the debug_poison option every launch is
+    preceded by kernels that fill all LDS and all VGPRs with NaN patterns -- the output must be bit-identical (both kernel
+    families; the narrow streamed nets too)."""
+    from dcscn_amd import engine
+    for name in ("L12_F196to48_x2", "L7_F32to8_x4_DS", "L7_F32to8_x2"):
+        cfg = oracle.make_config(**CONFIGS[name])
+        weights = oracle.synthetic_weights(cfg, seed=2)
+        x, x2 = synthetic_batch(2, 33, 48, cfg["scale"], seed=3)
+        for s16 in (True, False):
+            with engine.Engine(cfg, device=0) as eng:
+                eng.load_weights(weights, split16=s16)
+                y0 = eng.forward(x, x2)
+                eng.set_option("debug_poison", 3)
+                y1 = eng.forward(x, x2)
+            assert np.isfinite(y0).all() and np.array_equal(y0, y1), (name, s16)
 
 
 def test_errors_are_reported_not_fatal(oracle):
@@ -296,10 +378,10 @@ def test_full_size_bench_workload(oracle):
 
 # ---- opt-in graph rewrite: the linear tail as one 5x5 conv (include/dcscn.h "fold_linear_tail") ----------
 
-def _fold_engine(cfg, weights, fold=True):
+def _fold_engine(cfg, weights, fold=True, split16=None):
     from dcscn_amd import engine
     eng = engine.Engine(cfg, device=0)
-    eng.load_weights(weights, fold_tail=fold)
+    eng.load_weights(weights, fold_tail=fold, split16=split16)
     return eng
 
 
@@ -377,14 +459,16 @@ def test_folded_tail_not_applicable(oracle, variant):
 
 # ---- images larger than the workspace budget: haloed spatial windows (api.hip run_tiled) ----------------
 
+@pytest.mark.parametrize("split16", SPLIT16)
 @pytest.mark.parametrize("fold", [False, True])
 @pytest.mark.parametrize("case", [
     (dict(layers=3, filters=16, min_filters=8), 1, 70, 90),                 # x2, halo 3+1+1+1
+    (dict(layers=3, filters=40, min_filters=32, nin_filters=32, nin_filters2=16), 1, 60, 50),   # wide enough for conv3_h / conv_wino2
     (dict(layers=3, filters=16, min_filters=8, scale=3), 2, 45, 61),        # two images, x3
     (dict(layers=4, filters=12, min_filters=8, scale=4, pixel_shuffler_filters=4), 1, 64, 40),   # two PS stages
     (dict(layers=3, filters=16, min_filters=8), 1, 200, 20),                # tiled along one axis only
 ])
-def test_spatial_tiling(oracle, case, fold):
+def test_spatial_tiling(oracle, case, fold, split16):
     """With a workspace budget smaller than one image the library cuts windows with a receptive-field halo, runs
     them as a batch and stitches; the result must meet the same bar against the oracle of the WHOLE image (SAME
     padding only acts at true image borders) and agree with the untiled pass to rounding."""
@@ -393,7 +477,7 @@ def test_spatial_tiling(oracle, case, fold):
     weights = oracle.synthetic_weights(cfg, seed=2)
     x, x2 = synthetic_batch(n, h, w, cfg["scale"], seed=3)
     ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
-    with _fold_engine(cfg, weights, fold=fold) as eng:
+    with _fold_engine(cfg, weights, fold=fold, split16=split16) as eng:
         whole = eng.forward(x, x2)
         per_px = eng.workspace_bytes() // (n * h * w) + 1
         eng.set_option("workspace_budget_bytes", per_px * 30 * 34)          # windows of about 30 x 34 LR pixels

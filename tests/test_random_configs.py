@@ -39,8 +39,7 @@ def _draw(rng):
     return flags, n, h, w, opts
 
 
-@pytest.mark.parametrize("seed", range(200))
-def test_random_flag_surface(oracle, seed):
+def _run_draw(oracle, seed, split16):
     from dcscn_amd import engine
     rng = np.random.default_rng(1000 + seed)
     flags, n, h, w, opts = _draw(rng)
@@ -49,7 +48,7 @@ def test_random_flag_surface(oracle, seed):
     x, x2 = synthetic_batch(n, h, w, cfg["scale"], seed=seed + 1)
     ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
     with engine.Engine(cfg, device=0) as eng:
-        eng.load_weights(weights, winograd=opts["winograd"], fold_tail=opts["fold"])
+        eng.load_weights(weights, winograd=opts["winograd"], fold_tail=opts["fold"], split16=split16)
         y = eng.forward(x, x2)
         if opts["tile"] and h * w >= 600:
             per_px = eng.workspace_bytes() // (n * h * w) + 1
@@ -62,6 +61,17 @@ def test_random_flag_surface(oracle, seed):
                 assert float(np.max(np.abs(yt - ref))) <= 1e-4, (flags, n, h, w, opts)
     err = float(np.max(np.abs(y - ref)))
     assert np.isfinite(y).all() and err <= 1e-4, (err, flags, n, h, w, opts)
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_random_flag_surface(oracle, seed):
+    _run_draw(oracle, seed, None)                   # library default: split16 on
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_flag_surface_f32_kernels(oracle, seed):
+    """The first 60 draws again with split16 off: conv_wino2 / conv_nin / conv_igemm meet every drawn flag combination too."""
+    _run_draw(oracle, seed, False)
 
 
 @pytest.mark.parametrize("seed", range(16))

@@ -21,6 +21,9 @@
 #ifdef H16_HP
 #include "../dcscn-super-resolution_amd/csrc/conv3_hp.hpp"
 #endif
+#ifdef H16_H8
+#include "../dcscn-super-resolution_amd/csrc/conv3_h8.hpp"
+#endif
 #endif
 
 using namespace dcscn;
