@@ -220,18 +220,10 @@ def main():
         eng.forward_device(x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, PATCH, PATCH, stream)
 
     def step():
-        if share_gpu and world > 1:
-            # Test rig only (several ranks on ONE device): the ranks take turns.  Concurrent dispatch from several PROCESSES to one
-            # MI355X is not a supported deployment of this path -- with conv3_h kernels of another process in flight the results of
-            # a process are no longer bit-reproducible (even its pure f32 kernels: tools/determinism_check.py);
-            # one process per GPU, the real launch, is unaffected.
-            for turn in range(world):
-                if turn == rank:
-                    run_forward()
-                    eng.synchronize()
-                dist.barrier()
-        else:
-            run_forward()
+        # several ranks on ONE device (the single-GPU test rig, DCSCN_BENCH_SHARE_GPU=1) dispatch concurrently, like any other ranks:
+        # the r03 cross-process corruption was v_pk_fma_f32 misbehaving beside another process's MFMAs (tools/xproc_triage.hip,
+        # DESIGN.md section 6); the library is built without packed-f32 instructions since r04
+        run_forward()
 
     def fence():
         torch.cuda.synchronize()
@@ -307,15 +299,16 @@ def main():
         lr_pixels = n * PATCH * PATCH                         # this rank's
         global_lr_pixels = global_patches * PATCH * PATCH
         # dominant kernel: the Winograd 3x3 launches (CNN2..12, B2, and Up-PS in the layer-by-layer graph)
-        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino2", "conv3_h")
+        C3H = ("conv3_h", "conv3_h8")           # the split16 3x3 kernels: 4-wave workgroups / 8-wave ping-pong workgroups sharing the input tile
+        dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino2") + C3H
                and o["kernel_size"] == 3 and o["out_channels"] > 1]
         dom_kernels = sorted({o["kernel"] for o, _ in dom})
-        on_f16 = "conv3_h" in dom_kernels
+        on_f16 = any(k in C3H for k in dom_kernels)
         DOM_PREFIX[0] = "conv3_h" if on_f16 else "conv_wino"
         dom_peak = PEAK_F16_MFMA_TFLOPS if on_f16 else PEAK_F32_MFMA_TFLOPS
         # FLOPs the instruction stream would issue without channel padding: 3 f16 products per MAC (conv3_h), or the 16/36
         # of F(2x2,3x3) (conv_wino2)
-        dom_useful = dom_flop_useful = sum(2.0 * o["macs_per_lr_pixel"] * (3.0 if o["kernel"] == "conv3_h" else 16.0 / 36.0 if o["kernel"] == "conv_wino2" else 1.0)
+        dom_useful = dom_flop_useful = sum(2.0 * o["macs_per_lr_pixel"] * (3.0 if o["kernel"] in C3H else 16.0 / 36.0 if o["kernel"] == "conv_wino2" else 1.0)
                                             for o, _ in dom) * lr_pixels
         dom_flop = sum(2.0 * o["macs_per_lr_pixel"] for o, _ in dom) * lr_pixels
         dom_bytes = sum(float(o["bytes_per_lr_pixel"]) for o, _ in dom) * lr_pixels
@@ -327,7 +320,7 @@ def main():
         kernel_ms = sum(per_op_ms)
         per_kernel = {}
         for o, ms in zip(ops, per_op_ms):
-            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] in ("conv_igemm", "conv_wino2", "conv3_h") else "")
+            key = o["kernel"] + ("_%dx%d" % (o["kernel_size"], o["kernel_size"]) if o["kernel"] in ("conv_igemm", "conv_wino2") + C3H else "")
             per_kernel[key] = per_kernel.get(key, 0.0) + ms
         if args.ops:
             for o, ms in zip(ops, per_op_ms):
@@ -377,6 +370,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(executed / dom_peak, 4),
                 "useful_frac": round(dom_useful / (dom_ms * 1e-3) / 1e12 / dom_peak, 4) if dom_ms > 0 else None,
+                "algorithmic_frac": round(algorithmic / dom_peak, 4),
                 "frac_of_sustained": round(executed / SUSTAINED_F16_MFMA_TFLOPS, 4) if on_f16 else None,
                 "traffic": traffic["bytes_per_step"] if traffic else None,
                 "traffic_detail": traffic,
@@ -387,10 +381,13 @@ def main():
                                 "note": "direct-form f32 FLOPs of SURVEY.md 8(d) for the same launches per second, against the f32 "
                                         "MFMA / VALU peak the reference's arithmetic is bound by"},
                 "note": ("achieved = f16 FLOPs the kernel issues (3 products per MAC, input channels padded to 32, output channels to 16) "
-                         "per second of its own launch time (HIP events on the launch stream); frac = matrix-pipe utilisation against the "
-                         "dense f16 peak at the nominal 2.4 GHz; frac_of_sustained = against the 2.1 PFLOP/s the chip sustains with every "
-                         "SIMD issuing bare f16 MFMAs (8.0 ns per MFMA per SIMD = 2.0 GHz, profiles/r03_mfma_two_waves.txt; replayed PMC "
-                         "clock of this kernel: north_star.conv_3x3.*.sustained_clock_GHz); useful_frac leaves out the padding." if on_f16 else
+                         "per second of its own launch time (HIP events on the launch stream); frac = that against the dense f16 peak "
+                         "(2500, nominal 2.4 GHz); useful_frac = without the channel padding (3 x the algorithmic FLOPs: what f32-accurate "
+                         "arithmetic on this pipe has to issue); algorithmic_frac = the reference's own arithmetic (SURVEY 8(d) FLOPs, 1 x) "
+                         "against the same peak.  frac_of_sustained = against 2.1 PFLOP/s, this repository's bare-MFMA microbenchmark with "
+                         "constant operands (profiles/r03_mfma_two_waves.txt); MI355X_MICROARCH.md records 2.38-2.50 PFLOP/s for dense "
+                         "bf16 / f16, and with random operands in conv3_h's register pattern the same microbenchmark sustains 9.4 ns "
+                         "per MFMA = 1.78 PFLOP/s (profiles/r04_mfma_operands.txt)." if on_f16 else
                          "achieved = FLOPs the kernel issues (Winograd F(2x2,3x3): 16/36 of the direct form, plus channel padding to 16 / 8) "
                          "per second of its own launch time (HIP events on the launch stream); frac = matrix-pipe utilisation."),
                 "kernel_ms_per_step": round(dom_ms, 4),

@@ -99,6 +99,7 @@ int dcscn_create(const dcscn_config* cfg, int device, dcscn_handle* out) {
             rc = fail(h, DCSCN_ERR_HIP, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
             break;
         }
+        h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) { rc = fail(h, DCSCN_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); break; }
         if ((e = hipEventCreateWithFlags(&h->done_ev, hipEventDisableTiming)) != hipSuccess) { rc = fail(h, DCSCN_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e)); break; }
         if ((e = conv_init_kernels()) != hipSuccess) { rc = fail(h, DCSCN_ERR_HIP, "kernel attribute setup: %s", hipGetErrorString(e)); break; }
@@ -198,7 +199,10 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     memset(out, 0, sizeof *out);
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
     const bool s16 = h->split16 && op.h16.on && (h->split16_mask & (op.shape.nin ? 2 : 1));
-    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (s16 ? (op.shape.nin ? "conv_nin_h" : op.fold_s > 0 ? "conv5_h" : "conv3_h") : op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : "depthwise");
+    // conv3_h8 takes what c3e_eligible (conv3_h8.hip) accepts: two channel groups of 4..6 tiles, no depth_to_space, no residual
+    const bool h8 = s16 && h->conv3_h8 && !op.shape.nin && op.fold_s == 0 && op.h16.n_tiles == 2 && op.h16.nt >= 4 && op.h16.nt <= 6 && op.ps == 1 && !op.residual &&
+                    (op.act == ACT_ALPHA || op.act == ACT_NONE) && op.h16.n_chunks >= 3;
+    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (s16 ? (op.shape.nin ? "conv_nin_h" : op.fold_s > 0 ? "conv5_h" : h8 ? "conv3_h8" : "conv3_h") : op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
     out->out_channels = op.cout;
@@ -285,6 +289,10 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "split16")) {                  // any time: the f16 images are always built, the option picks the launch
         h->split16 = value != 0;
         h->split16_mask = value == 2 ? 1 : value == 3 ? 2 : 3;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "conv3_h8")) {                 // any time: the two kernels take the same filter image
+        h->conv3_h8 = value != 0;
         return DCSCN_OK;
     }
     if (!strcmp(key, "debug_digest")) {            // debug aid: a checksum of the whole workspace behind every launch (dcscn_debug_digests)

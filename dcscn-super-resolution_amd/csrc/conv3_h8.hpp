@@ -36,6 +36,11 @@
 
 namespace dcscn {
 
+// conv_wino2.hpp's glds16 with M0 declared clobbered instead of saved and restored around every piece (two s_mov fewer per DMA)
+__device__ __forceinline__ void glds16c(const void* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" DCSCN_GLDS_AUX : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+
 template <int NT>
 struct C3EGeom {
     static constexpr int THREADS = 512;
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         static_for<0, F>([&](auto r_) DCSCN_INL {
             constexpr int r = decltype(r_)::value;
             const int piece = (w4 + 4 * r) % pieces;
-            glds16(src + piece * 1024, f_off, lds0 + (unsigned)(G::F_BASE + (half * 3 + slot) * G::F_TAP_BYTES) + (unsigned)piece * 1024u);
+            glds16c(src + piece * 1024, f_off, lds0 + (unsigned)(G::F_BASE + (half * 3 + slot) * G::F_TAP_BYTES) + (unsigned)piece * 1024u);
         });
     };
     // address of tap `tt` of unit u's filter image (tt may run past the item: then it is a tap of the next unit)
@@ -347,21 +352,8 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                 constexpr int kx = step / 3, ky = step % 3;
                 // ================= LOAD phase of this tap =================
                 if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
-                if constexpr (step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>();        // the pieces issued in the previous load phase
-                {   // the tap two steps ahead: of this chunk, of the next one, of the packed tail, or of the next item
-                    constexpr int step2 = (step + 2) % 9;
-                    constexpr int ptap2 = (step2 % 3) * 3 + step2 / 3;
-                    const char* src;
-                    if constexpr (step + 2 < 9) src = cur.f_base + (size_t)(chunk * 9 + ptap2) * tap_stride;
-                    else src = !last_main ? cur.f_base + (size_t)((chunk + 1) * 9 + ptap2) * tap_stride
-                             : octs      ? cur.f_base + (size_t)(n_main * 9 + step2) * tap_stride
-                                         : nxt.f_base + (size_t)ptap2 * tap_stride;
-                    dma_f(src, (tslot + 2) % 3, CNT);
-                }
-                if constexpr (step == 0) load_in(li_base, li_ok, lchunk);
-                if constexpr (step >= 3) convert_store(std::integral_constant<int, step - 3>{}, li_all_in, li_ok, lchunk, ibuf ^ 1);
-                if constexpr (step == 0) { if (chunk == 0 && pending) epilogue(); }
-                // first fragments of this tap: the new B row(s) and the A fragments of tile 0
+                // first fragments of this tap, read FIRST (their latency runs under the rest of the phase): the new B row(s) and the
+                // A fragments of the first PFD tiles -- the tap's filter slot has been complete since the previous load phase's wait
                 if constexpr (ky == 0) {
                     int l = lane;
                     asm volatile("" : "+v"(l));
@@ -379,6 +371,20 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     wb[p] = *reinterpret_cast<const h8*>(fs + (2 * p) * 1024);       // (tiles past the half's last: stale bytes of its own slot, never used)
                     wa[p] = *reinterpret_cast<const h8*>(fs + (2 * p + 1) * 1024);
                 });
+                if constexpr (step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>();        // the pieces issued in the previous load phase
+                {   // the tap two steps ahead: of this chunk, of the next one, of the packed tail, or of the next item
+                    constexpr int step2 = (step + 2) % 9;
+                    constexpr int ptap2 = (step2 % 3) * 3 + step2 / 3;
+                    const char* src;
+                    if constexpr (step + 2 < 9) src = cur.f_base + (size_t)(chunk * 9 + ptap2) * tap_stride;
+                    else src = !last_main ? cur.f_base + (size_t)((chunk + 1) * 9 + ptap2) * tap_stride
+                             : octs      ? cur.f_base + (size_t)(n_main * 9 + step2) * tap_stride
+                                         : nxt.f_base + (size_t)ptap2 * tap_stride;
+                    dma_f(src, (tslot + 2) % 3, CNT);
+                }
+                if constexpr (step == 0) load_in(li_base, li_ok, lchunk);
+                if constexpr (step >= 3) convert_store(std::integral_constant<int, step - 3>{}, li_all_in, li_ok, lchunk, ibuf ^ 1);
+                if constexpr (step == 0) { if (chunk == 0 && pending) epilogue(); }
                 if constexpr (DBG == 1) pr_load += __builtin_readcyclecounter() - pr_a;
                 phase_barrier(pr_bl);
                 // ================= COMPUTE phase =================

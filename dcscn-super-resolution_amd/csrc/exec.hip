@@ -228,7 +228,8 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
             b.bias = op.h16.d_bias;
             b.tail_octs = op.h16.tail_octs;
             b.alpha = op.h16.d_alpha;
-            HIP_TRY(h, c3h_launch(op.h16.nt, b, op.h16.n_tiles, stream));
+            if (h->conv3_h8 && c3e_eligible(op.h16.nt, b, op.h16.n_tiles)) HIP_TRY(h, c3e_launch(op.h16.nt, b, op.h16.n_tiles, h->n_cus, stream));
+            else HIP_TRY(h, c3h_launch(op.h16.nt, b, op.h16.n_tiles, stream));
         }
         a.redo = b.redo;
         a.redo_check = 1;

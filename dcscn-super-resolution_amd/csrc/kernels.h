@@ -124,6 +124,11 @@ inline int c3h_tail_octs(int cin_phys) {
 inline int c3h_tail_steps(int octs) { return (9 * octs + 3) / 4; }
 hipError_t c3h_init_kernels();
 hipError_t c3h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
+// conv3_h8 (conv3_h8.hpp): conv3_h's launches with exactly two channel groups as ONE persistent 8-wave workgroup per CU -- the pixel
+// tile's input image staged once for both groups, the halves in ping-pong; same wpack16 image, same arguments, bit-identical results
+hipError_t c3e_init_kernels();
+bool c3e_eligible(int nt, const ConvArgs& a, int n_groups);
+hipError_t c3e_launch(int nt, const ConvArgs& a, int n_groups, int n_cus, hipStream_t stream);
 // conv5_h (conv5_h.hpp): the folded 5x5 tail on the f16 pipe; nt = ceil(4 ps^2 / 16) in {1, 3, 4}, one channel group, args as conv_launch's
 // fold launch plus args.wpack16 = pack_conv16 image with 25 taps, args.n_chunks = ceil(cin_phys / 32), args.inv_scale, args.redo
 hipError_t c5h_init_kernels();

@@ -30,6 +30,7 @@ hipError_t conv_init_kernels() {
     if (e == hipSuccess) e = nin_init_kernels();
     if (e == hipSuccess) e = nin_h_init_kernels();
     if (e == hipSuccess) e = c3h_init_kernels();
+    if (e == hipSuccess) e = c3e_init_kernels();
     if (e == hipSuccess) e = c5h_init_kernels();
     if (e == hipSuccess) stream_init_kernels();
     return e;

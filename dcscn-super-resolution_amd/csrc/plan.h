@@ -166,6 +166,8 @@ struct dcscn_ctx {
     bool profile = false;
     unsigned long long* d_digest = nullptr;   // debug_digest: one arena checksum per op of the last pass + one of y (dcscn_debug_digests)
     int debug_digest = 0;
+    bool conv3_h8 = true;                    // two-group 3x3 layers on conv3_h8 (option "conv3_h8"); off: conv3_h everywhere
+    int n_cus = 256;                         // compute units of the device (persistent launches)
     int debug_poison = 0;                    // debug: LDS (bit 0) / VGPRs (bit 1) of every CU are filled with NaN patterns in front of every launch
     // option "graph_replay": a forward whose arguments repeat (same pointers, shape, stream) is captured into a hipGraph the second
     // time it is seen and replayed from then on -- one graph launch instead of ~30 kernel launches per pass

@@ -75,7 +75,6 @@ class SuperResolution:
         self.pixel_shuffler_filters = flags.pixel_shuffler_filters
         self.self_ensemble = flags.self_ensemble
         self.ensemble_group = None          # evaluate.py: a shard.Group when the ensemble transforms of an image are spread over ranks
-        self.ensemble_serialize = False     # single-device test rig: ranks take turns on the GPU
         self.depthwise_separable = flags.depthwise_separable
 
         # image processing parameters (DCSCN.py:76-82)
@@ -322,7 +321,7 @@ class SuperResolution:
             # (image, transform) work items sharded over the ranks (evaluate.py); float64 mean in the reference's order
             output = self.ensemble_group.ensemble_mean(
                 x[:, :, None], x2[:, :, None], self.self_ensemble,
-                lambda a, b: eng.forward(a[None], b[None])[0], util.flip, serialize=self.ensemble_serialize)
+                lambda a, b: eng.forward(a[None], b[None])[0], util.flip)
         elif self.self_ensemble > 1:
             output = eng.forward_ensemble(x, x2, self.self_ensemble)            # float64, like np.zeros + +=
         else:

@@ -61,17 +61,7 @@ class Group:
         if self.world > 1:
             self._dist.barrier()
 
-    def by_turns(self, fn):
-        """Run fn() on one rank at a time (rank 0 first).  Only for the single-device test rig (DCSCN_SHARE_GPU=1): several
-        processes dispatching to ONE MI355X concurrently is not a supported deployment of this path."""
-        out = None
-        for turn in range(self.world):
-            if turn == self.rank:
-                out = fn()
-            self.barrier()
-        return out
-
-    def ensemble_mean(self, image, bicubic, n, forward_one, flip, serialize=False):
+    def ensemble_mean(self, image, bicubic, n, forward_one, flip):
         """Distributed self-ensemble of ONE image (DCSCN.py:559-573): transform t runs on rank t % world, the float32 results
         are gathered and every rank forms the float64 mean in the reference's order t = 0 .. n-1 (np.zeros float64, +=, / n).
         ``forward_one(x[h, w, 1], x2[sh, sw, 1]) -> [sh, sw, 1] float32``; ``flip(image, t, invert)`` = util.flip."""
@@ -83,7 +73,7 @@ class Group:
                 y = forward_one(np.ascontiguousarray(flip(image, t)), np.ascontiguousarray(flip(bicubic, t)))
                 parts.append((t, np.ascontiguousarray(flip(np.asarray(y, np.float32), t, invert=True))))
             return parts
-        parts = self.by_turns(mine) if (serialize and self.world > 1) else mine()
+        parts = mine()
         every = dict(self.gather(parts))
         out = np.zeros(every[0].shape, dtype=np.float64)
         for t in range(n):

@@ -94,18 +94,16 @@ def _evaluate_file(model, filename, save):
 
 def evaluate_model(model, test_data, group):
     test_filenames = util.get_files_in_directory(FLAGS.data_dir + "/" + test_data)
-    share = os.environ.get("DCSCN_SHARE_GPU") == "1"          # single-device test rig: the ranks take turns on the GPU
     if shard.split_ensemble(len(test_filenames), group.world, model.self_ensemble):
         # every rank walks every file; inside model.do the transforms of the image are spread over the ranks
-        model.ensemble_group, model.ensemble_serialize = group, share
-        results = [_evaluate_file(model, f, FLAGS.save_results and group.rank == 0) for f in test_filenames]
-        model.ensemble_group = None
+        model.ensemble_group = group
+        try:
+            results = [_evaluate_file(model, f, FLAGS.save_results and group.rank == 0) for f in test_filenames]
+        finally:
+            model.ensemble_group = None
     else:
         mine = shard.assign_longest_first(_pixel_counts(test_filenames), group.world)[group.rank]
-
-        def run():
-            return [(i,) + _evaluate_file(model, test_filenames[i], FLAGS.save_results) for i in mine]
-        tagged = group.gather(group.by_turns(run) if share and group.world > 1 else run())
+        tagged = group.gather([(i,) + _evaluate_file(model, test_filenames[i], FLAGS.save_results) for i in mine])
         results = [r[1:] for r in sorted(tagged)]             # back to file order
     if group.rank == 0:
         n = len(results)

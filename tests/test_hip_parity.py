@@ -101,7 +101,7 @@ def test_conv3_h_packed_last_chunk_channel_counts(oracle, filters):
     with engine.Engine(cfg, device=0) as eng:
         eng.load_weights(weights)
         kernels = [op["kernel"] for op in eng.ops() if op["kernel_size"] == 3 and op["in_channels"] == filters]
-        assert kernels and all(k == "conv3_h" for k in kernels), eng.ops()
+        assert kernels and all(k in ("conv3_h", "conv3_h8") for k in kernels), eng.ops()    # two channel groups -> conv3_h8, else conv3_h
         y = eng.forward(x, x2)
     rel = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
     print("filters=%d: residual-branch relative error %.3g" % (filters, rel))
@@ -306,6 +306,28 @@ def test_do_with_max_value(oracle, tmp_path, max_value, split16, monkeypatch):
         err = float(np.max(np.abs(np.asarray(y, np.float64) - ref)))
         print("do() max_value=%g self_ensemble=%d split16=%s: max-abs %.3g" % (max_value, n_ens, split16, err))
         assert y.shape == ref.shape and err <= MAX_ABS_TOL
+
+
+@pytest.mark.parametrize("name", ["L12_F196to48_x2", "L12_F196to48_x4", "wide-3"])
+def test_conv3_h8_is_bit_identical_to_conv3_h(oracle, name):
+    """Layers with two channel groups run on conv3_h8 (one persistent 8-wave workgroup per CU, the pixel tile's input staged once for
+    both groups, halves in ping-pong); the option conv3_h8 = 0 sends them to conv3_h.  Same arithmetic in the same order: same bits,
+    on ragged sizes (image-edge tiles take conv3_h8's general epilogue) and with more items than workgroups."""
+    from dcscn_amd import engine
+    flags = CONFIGS[name] if name in CONFIGS else dict(layers=3, filters=176, min_filters=112, filters_decay_gamma=1.0, nin_filters=48, nin_filters2=24)
+    cfg = oracle.make_config(**flags)
+    weights = oracle.synthetic_weights(cfg, seed=4)
+    for n, h, w in ((3, 48, 48), (2, 37, 50), (1, 130, 70)):
+        x, x2 = synthetic_batch(n, h, w, cfg["scale"], seed=5)
+        with engine.Engine(cfg, device=0) as eng:
+            eng.load_weights(weights)
+            on8 = [op["name"] for op in eng.ops() if op["kernel"] == "conv3_h8"]
+            assert on8, eng.ops()
+            y8 = eng.forward(x, x2)
+            eng.set_option("conv3_h8", 0)
+            assert not [op for op in eng.ops() if op["kernel"] == "conv3_h8"]
+            y4 = eng.forward(x, x2)
+        assert np.isfinite(y8).all() and np.array_equal(y8, y4), (name, n, h, w)
 
 
 def test_debug_poison_changes_nothing(oracle):

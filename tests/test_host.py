@@ -336,3 +336,28 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - 1024 * 48 * 48 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+
+
+def test_library_has_no_packed_f32_instructions(tmp_path):
+    """v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 return wrong low halves (lanes 48-63) when ANOTHER process's MFMA work shares the
+    SIMD (tools/xproc_triage.hip: victim cin1p vs cin1s beside aggressor mfma) -- the r03 cross-process
+    corruption.  build.py compiles every source with -target-feature -packed-fp32-ops; this checks the shipped code objects."""
+    import glob
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    lib = os.path.join(ROOT, "dcscn-super-resolution_amd", "libdcscn_hip.so")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.isfile(lib) and os.path.isfile(objdump)):
+        pytest.skip("library or llvm-objdump not present")
+    shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", "lib.so"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True)
+    objs = glob.glob(str(tmp_path / "lib.so.*gfx950*"))
+    assert objs, os.listdir(tmp_path)
+    packed = mfma = 0
+    for o in objs:
+        dis = subprocess.run([objdump, "-d", o], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+        packed += sum(1 for ln in dis.splitlines() if "v_pk_fma_f32" in ln or "v_pk_mul_f32" in ln or "v_pk_add_f32" in ln)
+        mfma += dis.count("v_mfma_f32_16x16x32_f16")
+    assert mfma > 1000, "disassembly did not find the kernels"
+    assert packed == 0, "%d packed-f32 VALU instructions in libdcscn_hip.so" % packed

@@ -4,6 +4,11 @@ bench.py --strong shards one seeded global batch into contiguous shards (dcscn-s
 DCSCN_BENCH_SHARE_GPU=1 the ranks share device 0 and rendezvous over gloo, so the multi-rank code path (shard bounds,
 per-rank engines, barrier + max-over-ranks timing, rank-ordered gather) runs on a single-GPU box.  Every output patch is
 hashed; the digest of the global batch in patch order must not depend on the number of ranks.
+
+The ranks dispatch to the device CONCURRENTLY (r03 made them take turns: a process running conv3_h made every other process on
+the GPU non-reproducible).  r04 found the cause -- packed-f32 VALU instructions return wrong low halves beside another process's
+MFMA work (tools/xproc_triage.hip, profiles/r04_xproc_triage.txt) -- and builds the library without them, so these tests are
+also the regression test of that fix: 2 and 3 processes with conv3_h / conv_nin_h kernels in flight at once, same bits as one.
 """
 import json
 import os
