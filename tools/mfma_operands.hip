@@ -78,7 +78,7 @@ int main() {
     hipMemcpy(src, h.data(), n * 16, hipMemcpyHostToDevice);
     for (int t : {256, 512}) {
         run<6, 2>(t, src, out); run<6, 0>(t, src, out); run<6, 1>(t, src, out);
-        run<3, 0>(t, src, out); run<3, 1>(t, src, out);
+        run<3, 0>(t, src, out); run<3, 1>(t, src, out);      // (these overflow to inf: MFMAs on non-finite accumulators take 50x longer)
     }
     return 0;
 }
