@@ -403,6 +403,48 @@ class SuperResolution:
             print("[%s] PSNR:%f, SSIM:%f" % (file_path, psnr, ssim))
         return psnr, ssim
 
+    def do_for_evaluate_many(self, file_paths, print_console=False):
+        """[(psnr, ssim, seconds)] of do_for_evaluate over the files, in order, as a three-stage pipeline: the
+        reference's loop (evaluate.py:89-107) is decode -> network -> PSNR / SSIM, strictly serial, and on this path the device is
+        ~5 % of an image's time (profiles/r03_c4_eval_profile.txt).  Here the PNG decode of the NEXT files runs on one worker thread,
+        the metric code (utilty.py:509-536, numpy / scipy: it releases the GIL) of the PREVIOUS ones on two more, and this thread
+        alone drives the engine (the handle is not thread safe) in file order.  Every value is computed by the same functions on
+        the same data as in do_for_evaluate: the results are identical.  `seconds` = wall clock of the whole call / number of files
+        (what a caller waits per file; the reference's figure is the serial time of each file)."""
+        import time
+        from concurrent.futures import ThreadPoolExecutor
+        n = len(file_paths)
+        if n == 0:
+            return []
+        t0 = time.time()
+
+        def decode(path):
+            return util.set_image_alignment(util.load_image(path, print_console=False), self.scale)
+
+        def metrics(true_y, output):
+            return util.compute_psnr_and_ssim(true_y, output, border_size=self.psnr_calc_border_size)
+
+        with ThreadPoolExecutor(max_workers=1) as dec, ThreadPoolExecutor(max_workers=2) as met:
+            ahead = 2
+            pending = {i: dec.submit(decode, file_paths[i]) for i in range(min(ahead, n))}
+            results = []
+            for i in range(n):
+                true_image = pending.pop(i).result()
+                if i + ahead < n:
+                    pending[i + ahead] = dec.submit(decode, file_paths[i + ahead])
+                if self._device_colour_path(true_image):
+                    true_y, output = self._ready_engine().evaluate_rgb(true_image, self.self_ensemble)
+                else:
+                    true_image, true_y, input_image, bicubic = self._evaluation_inputs(file_paths[i])
+                    output = None if true_y is None else self.do(input_image, bicubic)
+                results.append(None if true_y is None else met.submit(metrics, true_y, output))
+            values = [(None, None) if r is None else r.result() for r in results]
+        per_file = (time.time() - t0) / n
+        if print_console:
+            for path, (psnr, ssim) in zip(file_paths, values):
+                print("[%s] PSNR:%s, SSIM:%s" % (path, psnr, ssim))
+        return [(psnr, ssim, per_file) for psnr, ssim in values]
+
     def do_for_evaluate_with_output(self, file_path, output_directory, print_console=False):
         """As above, also writing the result images (DCSCN.py:616-670)."""
         filename, extension = os.path.splitext(file_path)

@@ -103,7 +103,12 @@ def evaluate_model(model, test_data, group):
             model.ensemble_group = None
     else:
         mine = shard.assign_longest_first(_pixel_counts(test_filenames), group.world)[group.rank]
-        tagged = group.gather([(i,) + _evaluate_file(model, test_filenames[i], FLAGS.save_results) for i in mine])
+        if not FLAGS.save_results and os.environ.get("DCSCN_EVAL_PIPELINE", "1") != "0":
+            # decode of the next files and PSNR / SSIM of the previous ones on worker threads, the device driven from this one
+            local = model.do_for_evaluate_many([test_filenames[i] for i in mine])
+            tagged = group.gather([(i,) + r for i, r in zip(mine, local)])
+        else:
+            tagged = group.gather([(i,) + _evaluate_file(model, test_filenames[i], FLAGS.save_results) for i in mine])
         results = [r[1:] for r in sorted(tagged)]             # back to file order
     if group.rank == 0:
         n = len(results)

@@ -60,6 +60,20 @@ def test_set14_psnr_matches_oracle(tmp_path, key, split16, monkeypatch):
     assert abs(float(np.mean(psnrs)) - g["set14"][key]["mean"]) <= 1e-3
 
 
+@pytest.mark.parametrize("ens", [1, 8])
+def test_pipelined_evaluation_gives_identical_values(tmp_path, ens):
+    """do_for_evaluate_many (decode of the next files / device / PSNR + SSIM of the previous files on different threads) returns
+    exactly the values of the serial do_for_evaluate loop (evaluate.py:89-107), Set14 incl. its grayscale image."""
+    g, m = _model(tmp_path, "L7_x2", self_ensemble=ens)
+    files = [os.path.join(GOLDEN, "set14", f) for f in g["set14"]["files"]]
+    serial = [m.do_for_evaluate(f) for f in files]
+    piped = m.do_for_evaluate_many(files)
+    m.close()
+    assert len(piped) == len(files)
+    for (p0, s0), (p1, s1, sec) in zip(serial, piped):
+        assert p0 == p1 and s0 == s1 and sec > 0
+
+
 def test_set5_psnr_self_ensemble_8(tmp_path):
     g, m = _model(tmp_path, "L7_x2", self_ensemble=8)
     psnrs = [m.do_for_evaluate(os.path.join(GOLDEN, "set5", f))[0] for f in g["files"]]
