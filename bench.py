@@ -101,9 +101,14 @@ def pmc_replay(dom_ms, nin_ms, algorithmic_bytes):
         ns = {"replayed": True, "source": os.path.basename(path)}
         if traffic and dom_ms > 0:
             gbs = traffic["bytes_per_step"] / (dom_ms * 1e-3) / 1e9
-            ns["hbm_3x3_stack"] = {"achieved_GBps": round(gbs, 1), "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
-                                   "note": "counter bytes (corrected) / this run's kernel time; the 3x3 stack is a dense f32 "
-                                           "contraction (AI 117-404 FLOP/B): MFMA bound, not HBM bound"}
+            alg_gbs = algorithmic_bytes / (dom_ms * 1e-3) / 1e9
+            ns["hbm_3x3_stack"] = {"achieved_GBps": round(gbs, 1), "algorithmic_GBps": round(alg_gbs, 1), "peak_GBps": PEAK_HBM_GBS,
+                                   "frac": round(gbs / PEAK_HBM_GBS, 4), "algorithmic_frac": round(alg_gbs / PEAK_HBM_GBS, 4),
+                                   "note": "counter bytes (corrected) and SURVEY 8(d) algorithmic bytes over this run's kernel time.  The "
+                                           "north_star's >= 0.5 of the HBM roofline is unreachable for this stack in f32-equivalent "
+                                           "arithmetic: 24.1 GB at 8 TB/s is 3.0 ms, the three f16 products per MAC alone are 7.3 ms at the "
+                                           "nominal 2.5 PFLOP/s (ceiling ~0.41), 10.3 ms at the 1.78 PFLOP/s the pipe sustains with "
+                                           "random operands (profiles/r04_mfma_operands.txt: ceiling ~0.29); the stack is MFMA bound"}
         for name, k in kernels.items():
             if (name.startswith("conv_nin") or name.startswith("conv_igemm<1,")) and "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
                 active = k["GRBM_GUI_ACTIVE"] / 8.0          # summed over the 8 XCDs

@@ -251,7 +251,10 @@ def _crc32c(data, crc=0):
     linear over GF(2), so the buffer is cut into _CRC_LANES equal segments whose registers advance together in numpy
     (one vector step per byte POSITION, not per byte), and the segment results are chained with the operator "advance the
     register over len(segment) zero bytes", itself tabulated bytewise from its action on the 32 unit vectors."""
-    data = bytes(data) if not isinstance(data, (bytes, bytearray, memoryview)) else data
+    if isinstance(data, memoryview):
+        data = data.cast("B") if data.format != "B" or data.ndim != 1 else data      # bytes, whatever the view's element type
+    elif not isinstance(data, (bytes, bytearray)):
+        data = bytes(data)
     state = (crc ^ 0xFFFFFFFF) & 0xFFFFFFFF
     n = len(data)
     seg = n // _CRC_LANES

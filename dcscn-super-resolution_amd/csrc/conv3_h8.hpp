@@ -1,6 +1,6 @@
 // conv3_h8: conv3_h's arithmetic (3x3 SAME conv + bias + activator, tf.nn.conv2d of helper/tf_graph.py:104-153, direct implicit GEMM on
 // v_mfma_f32_16x16x32_f16 with f16 (hi, lo) operands, three products per MAC: split16.hpp) with the workgroup rebuilt around what the
-// r04 probes measured (profiles/r04_conv3_h_probe.txt, r04_conv3_hp_probe.txt):
+// r04 probes measured (profiles/r04_conv3_h_probe.txt, r04_h16_conv3_harness.txt):
 //
 //   * a conv3_h wave needs ~2300 cycles per tap when it has its SIMD to itself -- 1152 of MFMAs and as much again of everything
 //     around them (barrier, filter DMA issue, LDS reads it has to wait for, staging of the next image) -- and two independent
@@ -24,7 +24,7 @@
 //   wait is in the load phase and costs nothing), so the first fragments of a tap can be read before the barrier that starts its
 //   compute phase.
 // * the workgroup is persistent (one per CU, items dealt statically: equal work, no competition inside a CU): the next item's first
-//   image and first taps are in flight during the last taps of the current one, the epilogue of a half (lean path as conv3_hp's) runs
+//   image and first taps are in flight during the last taps of the current one, the epilogue of a half (lean fast path) runs
 //   in its first load phase of the next item.
 // * LDS: 2 x 41.5 + 2 x 3 x NT x 2 KB + bias = 156 KB at NT = 6.  VGPRs: 96 accumulators + 32 B + 16 A (double buffered) + 24 staged.
 //
@@ -32,9 +32,14 @@
 // the pieces issued in the PREVIOUS load phase, so the count is the number of image loads issued behind them (6 after a step 0, else
 // 0); epilogue stores and anything else issued in between only make a wait longer than needed, never shorter.
 #pragma once
-#include "conv3_hp.hpp"
+#include "conv3_h.hpp"
 
 namespace dcscn {
+
+template <int N>
+__device__ __forceinline__ void c3p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS operations of this wave done, then the workgroup barrier; no fence semantics wanted (vector memory stays in flight across it)
+__device__ __forceinline__ void c3p_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // conv_wino2.hpp's glds16 with M0 declared clobbered instead of saved and restored around every piece (two s_mov fewer per DMA)
 __device__ __forceinline__ void glds16c(const void* sbase, unsigned voff, unsigned lds_dst) {

@@ -395,6 +395,8 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     dcscn_ctx::GraphKey gkey;
     gkey.x = x; gkey.x2 = x2; gkey.y = y; gkey.stream = stream; gkey.n = n; gkey.H = H; gkey.W = W;
     gkey.split16 = h->split16 ? h->split16_mask : 0;
+    gkey.nb = nb;                                        // the pass size (sub_batch_pixels / budget) shapes the launch sequence too
+    gkey.h8 = h->conv3_h8 ? 1 : 0;
     gkey.carve = (unsigned long long)h->carve_gen;
     const bool graphs = h->graph_replay && !h->profile;
     bool capturing = false;
@@ -406,8 +408,9 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         return DCSCN_OK;
     }
     if (graphs && gkey == h->graph_seen) {
-        HIP_TRY(h, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        capturing = true;
+        // a caller that is capturing this stream itself (or any other reason capture cannot start): plain launches, replay off for this key
+        if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) capturing = true;
+        else (void)hipGetLastError();
     }
     h->graph_seen = gkey;
     auto abandon_capture = [&]() {
@@ -461,19 +464,27 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     }
     if (capturing) {
         hipGraph_t g = nullptr;
-        HIP_TRY(h, hipStreamEndCapture(stream, &g));
+        hipError_t ce = hipStreamEndCapture(stream, &g);
         if (h->graph_exec) {
             (void)hipGraphExecDestroy(h->graph_exec);
             h->graph_exec = nullptr;
         }
-        const hipError_t ie = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (ie != hipSuccess) {
+        if (ce == hipSuccess) ce = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (ce == hipSuccess) ce = hipGraphLaunch(h->graph_exec, stream);
+        if (ce != hipSuccess) {
+            // nothing captured has run: forget the graph, forget the key, and issue this forward as plain launches
+            (void)hipGetLastError();
+            if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
             h->graph_exec = nullptr;
-            HIP_TRY(h, ie);
+            h->graph_seen = dcscn_ctx::GraphKey{};
+            const bool was = h->graph_replay;
+            h->graph_replay = false;
+            const int rr = run_forward(h, x, x2, y, n, H, W, stream);
+            h->graph_replay = was;
+            return rr;
         }
         h->graph_key = gkey;
-        HIP_TRY(h, hipGraphLaunch(h->graph_exec, stream));
     }
     HIP_TRY(h, hipEventRecord(h->done_ev, stream));
     h->last_stream = stream;

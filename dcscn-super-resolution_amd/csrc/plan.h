@@ -175,10 +175,11 @@ struct dcscn_ctx {
     struct GraphKey {
         const void *x = nullptr, *x2 = nullptr, *y = nullptr;
         void* stream = nullptr;
-        int n = 0, H = 0, W = 0, split16 = 0;
+        int n = 0, H = 0, W = 0, split16 = 0, nb = 0, h8 = 0;
         unsigned long long carve = 0;
         bool operator==(const GraphKey& o) const {
-            return x == o.x && x2 == o.x2 && y == o.y && stream == o.stream && n == o.n && H == o.H && W == o.W && split16 == o.split16 && carve == o.carve;
+            return x == o.x && x2 == o.x2 && y == o.y && stream == o.stream && n == o.n && H == o.H && W == o.W && split16 == o.split16 && nb == o.nb &&
+                   h8 == o.h8 && carve == o.carve;
         }
     };
     GraphKey graph_seen, graph_key;          // the previous forward's arguments; the arguments graph_exec was captured with

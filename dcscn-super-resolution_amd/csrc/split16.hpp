@@ -2,7 +2,9 @@
 // profiles/r03_f16x3_numerics.txt).
 //
 // An f32 operand x is carried as two f16 pieces, x = hi + lo with hi = f16(x) and lo = f16(x - hi) (x - hi is exact in f32,
-// so the pair holds x to 2^-23..2^-24 relative), and a product a*b is taken as  ah*bh + ah*bl + al*bh  -- three
+// so the pair holds x to 2^-22..2^-24 relative while lo is a normal f16, i.e. for |x| >= ~2^-3; below that lo is subnormal and the
+// pair has an absolute error floor of 2^-25 ~ 3e-8 -- weights are scaled per layer to stay clear of it, activations are not: see
+// include/dcscn.h "split16" and test_small_magnitude_inputs_on_split16), and a product a*b is taken as  ah*bh + ah*bl + al*bh  -- three
 // v_mfma_f32_16x16x{16,32}_f16 instead of four (eight) v_mfma_f32_16x16x4_f32, at 1/16 of their cycles per MAC.  Every
 // f16 x f16 product is exact in f32, the instruction sums its 16 / 32 products and adds them to the f32 accumulator, so the
 // result is at least as accurate as the f32 fma chain the f32-input MFMA computes (measured: 0.3-0.7x its error).  The
@@ -14,8 +16,11 @@
 //   * activations are split in registers, unscaled: |x| < 65520 is required for hi to be finite.  A value beyond that
 //     makes the accumulators of every output it feeds inf / NaN; the epilogue detects non-finite outputs and raises the
 //     `redo` flag of its unit (pixel block / pixel tile), and the f32 kernel launched behind it recomputes exactly the
-//     flagged units (and nothing else: it exits at once where the flag is clear).  So the path is exact-f32 safe for ANY
-//     input, and deterministic per unit whatever else is in the batch.
+//     flagged units (and nothing else: it exits at once where the flag is clear).  So the path is safe for ANY finite f32
+//     input, and deterministic per unit whatever else is in the batch (a unit of the 1x1 GEMM is 256 consecutive pixels of the
+//     flat pixel list and can straddle two images: include/dcscn.h).  The flag is raised on NON-FINITE accumulators only -- the
+//     right trigger for |x| >= 65520; finite-but-huge inputs (6.5e4 > |x| >> 255) are covered by the 2^-22 relative bound of the
+//     split, not by the fallback.
 #pragma once
 #include "conv_igemm.hpp"
 

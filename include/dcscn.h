@@ -160,7 +160,9 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * oracle at the same 1e-4 bar).  0 = the escape hatch: execute the reference's layers one by one.  Ignored where the
  * graph has no such tail: separable convs, transposed-conv upsampler, reconstruct_layers > 1, cnn_size != 3 -- and,
  * with the default value 1, where the composite would be MORE work than the layers (pixel shufflers to fewer than 12
- * channels at x2: the c-DCSCN nets); 2 folds there too.
+ * channels at x2: the c-DCSCN nets); 2 folds there too.  The work rule is evaluated ONCE, in dcscn_finalize, for the "split16"
+ * value in force then (a one-tile composite is cheap on conv5_h and folds; on the f32 kernel it would not): a handle whose
+ * split16 option is flipped afterwards keeps the plan it was finalized with.
  * "dense_features" (default 1; before dcscn_finalize only): every feature layer stores into its own dense NHWC buffer and
  * the 1x1 layer(s) that consume tf.concat (DCSCN.py:234) walk the list of buffers, instead of all layers sharing one
  * [n, h, w, sum C_i] tensor -- same bits, full cache lines.  0 = one concat tensor.  Ignored where a consumer of the
@@ -172,10 +174,21 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * differ by accumulation order only).
  * "split16" (default 1; any time): the 3x3 convs the Winograd kernel would take and the wide 1x1 convs run their contraction
  * on the f16 matrix pipe at f32 accuracy -- every f32 operand as an f16 (hi, lo) pair, three products per MAC, f32
- * accumulation; measured error at the f32 kernels' level (profiles/r03_f16x3_numerics.txt).  An activation beyond the f16 range
- * (|x| >= 65520) makes the affected outputs non-finite; the kernel flags their 16x16 tile / 256-pixel block and the f32
- * kernel, launched behind it, recomputes exactly the flagged units -- so the result is f32-exact-safe for any input and does
- * not depend on what else is in the batch.  0 = the pure f32 kernels (conv_wino2 / conv_nin).
+ * accumulation; measured error at the f32 kernels' level (profiles/r03_f16x3_numerics.txt).  Weights are scaled
+ * by a power of two per layer before the split; activations are split unscaled, so below |x| ~ 2^-3 their `lo` piece is an f16
+ * subnormal and the pair carries an ABSOLUTE error floor of ~3e-8 per element instead of a relative 2^-22 -- immaterial for the
+ * network's data (tested: inputs in [0, 1] as --max_value=1 feeds them meet the same 5e-6 bar on the bare branch,
+ * test_small_magnitude_inputs_on_split16), but not "f32 accuracy for any input".  An activation beyond the f16 range
+ * (|x| >= 65520) makes the affected outputs non-finite; the kernel flags their unit and the f32 kernel, launched behind it,
+ * recomputes exactly the flagged units, so the result is safe for any finite f32 input.  Unit = a 16x16 pixel tile of one image
+ * for the 3x3 / 5x5 kernels; a block of 256 consecutive pixels of the flat pixel list for the 1x1 GEMM -- such a block can straddle
+ * two images (H * W not a multiple of 256), so an overflow in image A may send up to 255 pixels of image B to the f32 kernel:
+ * B's values then differ from an all-split16 run at rounding level (both are within the parity bars), i.e. results are
+ * independent of the rest of the batch per tile for 3x3 layers and up to that block granularity for 1x1 layers.
+ * 0 = the pure f32 kernels (conv_wino2 / conv_nin).
+ * "conv3_h8" (default 1; any time): 3x3 layers whose output channels form two channel groups (7 .. 12 tiles of 16) run on
+ * conv3_h8 -- one persistent 8-wave workgroup per CU that stages a pixel tile's input once for both groups -- instead of two
+ * conv3_h workgroups per tile; same filter image, bit-identical results.
  * "graph_replay" (default 0; any time): a dcscn_forward_device call whose arguments repeat (same x / x2 / y pointers, shape and
  * stream) is captured into a hipGraph the second time it is seen and replayed from then on: one graph launch instead of the
  * pass's ~30 kernel launches (the launch gaps are 0.4 % of a 1024-patch pass of the L12 model, 3 % for the narrow nets).  The

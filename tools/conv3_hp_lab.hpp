@@ -1,3 +1,5 @@
+// LAB KERNEL (tools/h16_tune -DH16_HP; not part of the library): measured neutral against conv3_h (profiles/r04_h16_conv3_harness.txt),
+// its persistent item loop and lean epilogue live on in csrc/conv3_h8.hpp.
 // conv3_hp: conv3_h's arithmetic and LDS pipeline (conv3_h.hpp: 3x3 SAME conv + bias + activator, tf.nn.conv2d of
 // helper/tf_graph.py:104-153, as a direct implicit GEMM on v_mfma_f32_16x16x32_f16 with f16 (hi, lo) operands, 3 products per
 // MAC) as a PERSISTENT kernel: two workgroups per CU for the whole launch, each pulling (pixel tile, channel group) items from
@@ -25,7 +27,7 @@
 // waits longer).  The counts per step are spelled out at the waits.  LDS-DMA must not be in flight when the workgroup ends
 // (the LDS is handed to the next one): vmcnt(0) before s_endpgm.
 #pragma once
-#include "conv3_h.hpp"
+#include "../dcscn-super-resolution_amd/csrc/conv3_h.hpp"
 
 namespace dcscn {
 
@@ -54,9 +56,9 @@ struct C3Next {              // what the item in progress needs to know about th
 };
 
 template <int N>
-__device__ __forceinline__ void c3p_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void c3pl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // LDS operations of this wave done, then the workgroup barrier; no fence semantics wanted (vector memory stays in flight across it)
-__device__ __forceinline__ void c3p_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void c3pl_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // DBG (tuner only): 1 = shader-clock probes per wave through a.srctab: [0] entry, [1] exit, [2] items, [3] sum of epilogues,
 // [4] sum of chunk boundaries (barrier + image write), [5] sum of (wait + barrier) per tap, [6] HW_ID, [7] XCC_ID
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
         const int got = fetch(3);
         post(got);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        c3p_barrier();
+        c3pl_barrier();
         const int id0 = collect();
         decode(id0, cur, std::true_type{});
         decode(id0 + 8, nxt, std::false_type{});
@@ -273,11 +275,11 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
                 if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
                 // operations issued behind this tap's pieces: step 0: the DMA of step 8 (+ the previous epilogue); step 1: the DMA and the
                 // image loads of step 0 (+ the previous epilogue); step 2: those loads and the DMA of step 1; later steps: one DMA
-                if constexpr (step == 0) { if (first) c3p_wait_vm<F + E_FULL>(); else c3p_wait_vm<F>(); }
-                else if constexpr (step == 1) { if (first) c3p_wait_vm<F + L + E_FULL>(); else c3p_wait_vm<F + L>(); }
-                else if constexpr (step == 2) c3p_wait_vm<F + L>();
-                else c3p_wait_vm<F>();
-                c3p_barrier();
+                if constexpr (step == 0) { if (first) c3pl_wait_vm<F + E_FULL>(); else c3pl_wait_vm<F>(); }
+                else if constexpr (step == 1) { if (first) c3pl_wait_vm<F + L + E_FULL>(); else c3pl_wait_vm<F + L>(); }
+                else if constexpr (step == 2) c3pl_wait_vm<F + L>();
+                else c3pl_wait_vm<F>();
+                c3pl_barrier();
                 if constexpr (DBG == 1) pr_bar += __builtin_readcyclecounter() - pr_a;
                 {   // the tap two steps ahead: of this chunk, of the next one, of the packed tail, or of the next item
                     const char* src;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
                     static_for<2 * (step - 3), (2 * (step - 3) + 2 < L ? 2 * (step - 3) + 2 : L)>([&](auto r_) DCSCN_INL { convert_in(r_, li_all_in, li_ok, lchunk); });
             });
             if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
-            c3p_barrier();                                    // every wave is past its last read of this chunk's image
+            c3pl_barrier();                                    // every wave is past its last read of this chunk's image
             store_in();                                       // made visible by the barrier in front of the next tap
             if constexpr (DBG == 1) pr_cb += __builtin_readcyclecounter() - pr_a;
         }
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
             asm volatile("" : "+v"(l));
             auto tail_step = [&](int step, auto first_c) DCSCN_INL {
                 constexpr bool FIRST = decltype(first_c)::value;             // step 0, peeled: the image loads must not sit under a condition
-                if (FIRST) c3p_wait_vm<F>(); else if (step == 1 || step == 2) c3p_wait_vm<F + L>(); else c3p_wait_vm<F>();
-                c3p_barrier();
+                if (FIRST) c3pl_wait_vm<F>(); else if (step == 1 || step == 2) c3pl_wait_vm<F + L>(); else c3pl_wait_vm<F>();
+                c3pl_barrier();
                 {
                     const int k = step + 2 - n_tail;          // >= 0: step k of the next item (packed taps 0 and 3)
                     const char* src = k < 0 ? cur.f_base + (size_t)(n_main * 9 + step + 2) * G::F_TAP_BYTES : nxt.f_base + (size_t)(3 * k) * G::F_TAP_BYTES;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
             for (int step = 1; step < n_tail; ++step) tail_step(step, std::false_type{});
             static_for<0, L>([&](auto r_) DCSCN_INL { convert_in(r_, nxt.all_in, nxt.ok_mask, 0); });
             if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
-            c3p_barrier();
+            c3pl_barrier();
             store_in();
             if constexpr (DBG == 1) pr_cb += __builtin_readcyclecounter() - pr_a;
         }

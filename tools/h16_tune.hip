@@ -19,7 +19,7 @@
 #ifdef H16_CONV3
 #include "../dcscn-super-resolution_amd/csrc/conv3_h.hpp"
 #ifdef H16_HP
-#include "../dcscn-super-resolution_amd/csrc/conv3_hp.hpp"
+#include "conv3_hp_lab.hpp"
 #endif
 #ifdef H16_H8
 #include "../dcscn-super-resolution_amd/csrc/conv3_h8.hpp"
