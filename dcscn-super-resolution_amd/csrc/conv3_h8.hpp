@@ -69,7 +69,9 @@ struct C3EGeom {
 // NT = channel tiles of half 0, C1 = of half 1 (NT or NT - 1; 0 for a one-tile layer): launch constants -- the host instantiates the
 // pair a layer needs, every loop over tiles is straight-line code (a branch around a tile makes the compiler wait for ALL outstanding
 // LDS reads in front of every tile, and merging code variants cost 60 VGPRs in copies of the accumulators).
-template <int NT, int C1, int DBG = 0>
+// NTP = channel tiles per group in the filter image when that is a launch constant too (two-group layers: NTP = NT, every tap address an
+// immediate offset), 0 = args.nt_pack (tuner: one group split between the halves)
+template <int NT, int C1, int DBG = 0, int NTP = NT>
 __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
     static_assert(C1 == NT || C1 == NT - 1, "half 1 takes as many tiles as half 0 or one fewer");
     constexpr int PFD = C3E_PFD < NT ? C3E_PFD : (NT > 1 ? NT - 1 : 1), NB = PFD + 1;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave >> 2, w4 = wave & 3;
     const int H = a.H, W = a.W;
-    const int n_groups = a.n_groups, ntp = a.nt_pack;
+    const int n_groups = a.n_groups, ntp = NTP ? NTP : a.nt_pack;
     const int n_pairs = (n_groups + 1) >> 1;
     const int n_units = a.N * a.tiles_y * a.tiles_x * n_pairs;
     const int n_chunks = a.n_chunks;
@@ -187,12 +189,12 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         }
     };
     // one tap of this half's filters -> ring slot
-    auto dma_f = [&](const char* src, int slot, int cnt) DCSCN_INL {
+    auto dma_f = [&](const char* src, int slot /* byte offset of the ring slot */, int cnt) DCSCN_INL {
         const int pieces = cnt > 0 ? 2 * cnt : 1;
         static_for<0, F>([&](auto r_) DCSCN_INL {
             constexpr int r = decltype(r_)::value;
             const int piece = (w4 + 4 * r) % pieces;
-            glds16c(src + piece * 1024, f_off, lds0 + (unsigned)(G::F_BASE + (half * 3 + slot) * G::F_TAP_BYTES) + (unsigned)piece * 1024u);
+            glds16c(src + piece * 1024, f_off, lds0 + (unsigned)slot + (unsigned)piece * 1024u);
         });
     };
     // address of tap `tt` of unit u's filter image (tt may run past the item: then it is a tap of the next unit)
@@ -214,9 +216,11 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
     if (!cur.valid) return;
     decode(id + (int)gridDim.x, nxt);
     int ibuf = 0;                                              // image buffer of the chunk being computed
-    int tslot = 0;                                             // ring slot of the tap being computed (both halves count alike)
-    dma_f(tap_src(cur, nxt, 0), 0, CNT);
-    dma_f(tap_src(cur, nxt, 1), 1, CNT);
+    // byte offsets of this half's three ring slots, in the order (this tap, next tap, tap after next) at step % 3 == 0 of a chunk:
+    // nine taps per chunk leave the order alone, the packed tail rotates it once per step
+    int sl0 = G::F_BASE + (half * 3 + 0) * G::F_TAP_BYTES, sl1 = G::F_BASE + (half * 3 + 1) * G::F_TAP_BYTES, sl2 = G::F_BASE + (half * 3 + 2) * G::F_TAP_BYTES;
+    dma_f(tap_src(cur, nxt, 0), sl0, CNT);
+    dma_f(tap_src(cur, nxt, 1), sl1, CNT);
     load_in(cur.a_base, cur.ok_mask, 0);
     static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, cur.all_in, cur.ok_mask, 0, 0); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     xh[row & 3] = *reinterpret_cast<const h8*>(smem + b_hi + row * G::ROW_BYTES);
                     xl[row & 3] = *reinterpret_cast<const h8*>(smem + (b_hi ^ 16) + row * G::ROW_BYTES);
                 });
-                const char* fs = smem + G::F_BASE + (half * 3 + tslot) * G::F_TAP_BYTES + a_lane;
+                const char* fs = smem + (step % 3 == 0 ? sl0 : step % 3 == 1 ? sl1 : sl2) + a_lane;
                 static_for<0, PFD>([&](auto p_) DCSCN_INL {
                     constexpr int p = decltype(p_)::value;
                     wb[p] = *reinterpret_cast<const h8*>(fs + (2 * p) * 1024);       // (tiles past the half's last: stale bytes of its own slot, never used)
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     else src = !last_main ? cur.f_base + (size_t)((chunk + 1) * 9 + ptap2) * tap_stride
                              : octs      ? cur.f_base + (size_t)(n_main * 9 + step2) * tap_stride
                                          : nxt.f_base + (size_t)ptap2 * tap_stride;
-                    dma_f(src, (tslot + 2) % 3, CNT);
+                    dma_f(src, (step + 2) % 3 == 0 ? sl0 : (step + 2) % 3 == 1 ? sl1 : sl2, CNT);
                 }
                 if constexpr (step == 0) load_in(li_base, li_ok, lchunk);
                 if constexpr (step >= 3) convert_store(std::integral_constant<int, step - 3>{}, li_all_in, li_ok, lchunk, ibuf ^ 1);
@@ -418,7 +422,6 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                 if constexpr (DBG == 1) pr_comp += __builtin_readcyclecounter() - pr_a;
                 phase_barrier(pr_bc);
                 ++tt;
-                tslot = tslot == 2 ? 0 : tslot + 1;
             });
             ibuf ^= 1;
         }
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                 constexpr bool FIRST = decltype(first_c)::value;
                 if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
                 if (!FIRST && step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>();
-                dma_f(tap_src(cur, nxt, tt + 2), (tslot + 2) % 3, CNT);
+                dma_f(tap_src(cur, nxt, tt + 2), sl2, CNT);
                 if constexpr (FIRST) load_in(nxt.a_base, nxt.ok_mask, 0);
                 if (!FIRST && step == 2) static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, nxt.all_in, nxt.ok_mask, 0, ibuf ^ 1); });
                 const int pair = 4 * step + (l >> 4);
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     xh[m] = *reinterpret_cast<const h8*>(smem + b + m * G::ROW_BYTES);
                     xl[m] = *reinterpret_cast<const h8*>(smem + (b ^ 16) + m * G::ROW_BYTES);
                 });
-                const char* fs = smem + G::F_BASE + (half * 3 + tslot) * G::F_TAP_BYTES + a_lane;
+                const char* fs = smem + sl0 + a_lane;
                 static_for<0, PFD>([&](auto p_) DCSCN_INL {
                     constexpr int p = decltype(p_)::value;
                     wb[p] = *reinterpret_cast<const h8*>(fs + (2 * p) * 1024);       // (tiles past the half's last: stale bytes of its own slot, never used)
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                 if constexpr (DBG == 1) pr_comp += __builtin_readcyclecounter() - pr_a;
                 phase_barrier(pr_bc);
                 ++tt;
-                tslot = tslot == 2 ? 0 : tslot + 1;
+                { const int t = sl0; sl0 = sl1; sl1 = sl2; sl2 = t; }   // the ring moves on by one slot per tail step
             };
             tail_step(0, std::true_type{});
             for (int step = 1; step < n_tail; ++step) tail_step(step, std::false_type{});

@@ -364,6 +364,7 @@ class SuperResolution:
             util.save_image(output_folder + filename + "_bicubic_y" + extension, scaled_image)
             image = self.do(org_image)
         util.save_image(output_folder + filename + "_result" + extension, image)
+        util.flush_saves_unless_deferred()                  # the PNGs are encoded on worker threads (imaging.save_image)
 
     def _device_colour_path(self, image):
         """uint8 RGB through the device colour / bicubic kernels: they reproduce the float64 numpy colour math and
@@ -484,8 +485,10 @@ class SuperResolution:
             util.save_image(output_directory + file_path, true_image)
             util.save_image(output_directory + filename + "_result" + extension, output_image)
         else:
+            util.flush_saves_unless_deferred()
             return None, None
 
+        util.flush_saves_unless_deferred()                  # the PNGs are encoded on worker threads (imaging.save_image)
         if print_console:
             print("[%s] PSNR:%f, SSIM:%f" % (filename, psnr, ssim))
         return psnr, ssim

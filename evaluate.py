@@ -61,7 +61,8 @@ def main(not_parsed_args):
                 evaluate_bicubic(model, test_data, group)
 
         for test_data in test_list:
-            evaluate_model(model, test_data, group)
+            with util.deferred_saves():                        # --save_results: the PNGs of a data set are encoded on worker threads
+                evaluate_model(model, test_data, group)
     group.close()
 
 
