@@ -7,30 +7,44 @@
 //     workgroups per CU hide only a quarter of that from each other: their non-MFMA phases are not forced apart;
 //   * every pixel tile's input is fetched, split into (hi, lo) and written to LDS once per channel GROUP (2.5x the algorithmic reads).
 //
-// Here ONE workgroup of 8 waves per CU owns a pixel tile for ALL its output channels: waves 0-3 (half 0) take one channel group,
-// waves 4-7 (half 1) the other (or the other half of the tiles of a single group), wave w and w + 4 share a SIMD, and the two halves
-// run in PING-PONG between workgroup barriers: while one half issues nothing but MFMAs (and the LDS reads feeding them) for its tap,
-// the other does everything else for ITS next tap -- waits for its filter DMA, issues the DMA two taps ahead, stages a slice of the
-// next image, and reads the first fragments of its tap into registers -- so that the matrix pipe of every SIMD goes from one wave
-// straight to the other at each barrier.
+// Here ONE persistent workgroup of 8 waves per CU owns a pixel tile for ALL its output channels: waves 0-3 (half 0) take one channel
+// group, waves 4-7 (half 1) the other (or the other half of the tiles of a single group), wave w and w + 4 share a SIMD.  Per tap a
+// half has a LOAD part (everything but MFMAs: the first fragments of the tap read into registers, filter DMA two taps ahead, a slice of
+// the next image staged, the epilogue of the previous item) and a COMPUTE part (12 MFMAs per channel tile and the LDS reads feeding
+// them, straight-line).  The halves run them in OPPOSITE order between ONE workgroup barrier per tap:
 //
-//   half 0:  LOAD(0) | COMPUTE(0) | LOAD(1) | COMPUTE(1) | ...
-//   half 1:          | LOAD(0)    | COMPUTE(0) | LOAD(1) | COMPUTE(1) | ...           ( | = s_barrier )
+//   half 0:  | LOAD(t)      COMPUTE(t) | LOAD(t+1)    COMPUTE(t+1) | ...
+//   half 1:  | COMPUTE(t-1) LOAD(t)    | COMPUTE(t)   LOAD(t+1)    | ...                   ( | = s_barrier )
+//
+// so that a SIMD's matrix pipe goes from one wave to the other inside a segment without anybody waiting at a barrier for it (the
+// first r04 build separated the parts by a second barrier -- C3E_SB = 0, kept for the tuner: a segment then lasted as long as its
+// slowest wave, twice per tap).  Half 1 runs at s_setprio 1: its MFMAs and, behind them, its load part win the issue arbitration
+// against the partner wave of the SIMD (-4 % on the two-group layers; raising the priority per phase instead, or for half 0, gains
+// nothing: profiles/r04_h16_conv3_harness.txt).
 //
 // * input image: ONE (hi, lo) image per 32-channel chunk for both halves, double buffered (2 x 41.5 KB): the 2592 (pixel, channel quad)
-//   items of chunk c + 1 are loaded at step 0 of chunk c by all 512 threads (6 loads each), split one round per step at steps 3..8 and
-//   written straight into the other buffer -- no chunk-boundary barrier, no second fetch for the second channel group.
-// * filters: a ring of three tap slots per half, filled by LDS-DMA two taps ahead; a tap's pieces are waited for ONE tap early (the
-//   wait is in the load phase and costs nothing), so the first fragments of a tap can be read before the barrier that starts its
-//   compute phase.
-// * the workgroup is persistent (one per CU, items dealt statically: equal work, no competition inside a CU): the next item's first
-//   image and first taps are in flight during the last taps of the current one, the epilogue of a half (lean fast path) runs
-//   in its first load phase of the next item.
-// * LDS: 2 x 41.5 + 2 x 3 x NT x 2 KB + bias = 156 KB at NT = 6.  VGPRs: 96 accumulators + 32 B + 16 A (double buffered) + 24 staged.
+//   items of chunk c + 1 are loaded at step 0 of chunk c by all 512 threads (6 loads each, hand-written so that the compiler's wait
+//   bookkeeping -- which cannot see the LDS-DMA instructions issued in between -- does not wait for the youngest DMA in front of every
+//   use), split one round per step at steps 3..8 and written straight into the other buffer: no chunk-boundary barrier, no second
+//   fetch for the second channel group.
+// * filters: a ring of three tap slots per half, filled by LDS-DMA two taps ahead.  Half 0 issues tap t + 2 in LOAD(t) (its slot was
+//   last read in COMPUTE(t - 1), before the barrier) and waits for tap t + 1 at the END of COMPUTE(t), right in front of the barrier
+//   that publishes it: two segments of latency budget.  Half 1 may not issue tap t + 2 before the barrier behind its LOAD(t) (sibling
+//   waves still read the slot in COMPUTE(t - 1)), so it issues right behind that barrier and waits at the end of LOAD(t + 1).  Either
+//   way a tap's slot is complete one segment before its compute part, so the tap's first fragments are read in the load part.
+// * persistent, items (pixel tiles) dealt statically -- equal work, no competition inside a CU: the next item's first image and first
+//   taps are in flight during the last taps of the current one, the epilogue of a half (lean fast path) runs in its first load part
+//   of the next item.
+// * LDS: 2 x 41.5 + 2 x 3 x NT x 2 KB + bias = 156 KB at NT = 6.  VGPRs: 96 accumulators + 32 B + 16 A (ring of 3 tiles) + 24 staged.
 //
-// vmcnt bookkeeping: per load phase F DMA instructions, then (step 0 only) 6 image loads; the wait at the head of a load phase needs
-// the pieces issued in the PREVIOUS load phase, so the count is the number of image loads issued behind them (6 after a step 0, else
-// 0); epilogue stores and anything else issued in between only make a wait longer than needed, never shorter.
+// vmcnt bookkeeping (a wave's vector-memory operations retire in order; anything issued that the counts below do not name -- epilogue
+// stores -- only makes a wait longer than needed, never shorter).  F = DMA instructions per wave and tap, 6 = image loads of a step 0.
+//   half 0, end of COMPUTE(t): the pieces of LOAD(t - 1) must have landed; younger: LOAD(t)'s F pieces, plus the six image loads when
+//     step t or t - 1 is a step 0  ->  vmcnt(F + 6) at steps 0 and 1, vmcnt(F) otherwise; the wait at step 2 thereby completes the
+//     image loads before their first use at step 3.  Packed tail: the same with its steps 0 / 1, and vmcnt(F) in front of step 2's
+//     conversion.
+//   half 1, end of LOAD(t): the pieces issued behind the previous barrier; younger: only this part's image loads  ->  vmcnt(6) at a
+//     step 0, vmcnt(0) otherwise.
 #pragma once
 #include "conv3_h.hpp"
 
@@ -63,6 +77,18 @@ struct C3EGeom {
 
 // DBG (tuner only) 1: per wave through a.srctab: [0] entry, [1] exit, [2] items, [3] sum of load phases, [4] sum of compute phases,
 // [5] sum of the waits at the barrier ending a load phase, [6] same for compute phases, [7] sum of epilogues
+#ifndef C3E_SB
+#define C3E_SB 1           // 1: one workgroup barrier per tap (see the header); 0: the two-barrier ping-pong of the first r04 build
+#endif
+#ifndef C3E_ABL
+#define C3E_ABL 0          // tuner only (results wrong): 1 no filter DMA, 2 no image staging, 4 no A-fragment reads, 8 no MFMAs, 16 no B-row reads
+#endif
+#ifndef C3E_PRIO
+#define C3E_PRIO 2         // waves of half (C3E_PRIO - 1) run at s_setprio 1 for the whole kernel; 0 = nobody
+#endif
+#ifndef C3E_PRIO_LEVEL
+#define C3E_PRIO_LEVEL 1
+#endif
 #ifndef C3E_PFD
 #define C3E_PFD 2          // A fragments are read this many channel tiles ahead of their MFMAs (the first PFD tiles in the load phase)
 #endif
@@ -158,7 +184,9 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         static_for<0, L>([&](auto r_) DCSCN_INL {
             constexpr int r = decltype(r_)::value;
             const int pix = ((mask >> r) & 1u) ? hrow * W + hcol : W + 1;
-            gin[r] = *reinterpret_cast<const f32x4*>(base + (size_t)((unsigned)(pix * stride4) + coff));
+            // by hand: the compiler's own vmcnt bookkeeping does not see the LDS-DMA instructions between these loads and their use and
+            // would wait for the youngest of THEM in front of every round of convert_store; the waits below cover these loads
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(gin[r]) : "v"((unsigned)(pix * stride4) + coff), "s"(base) : "memory");
             hcol += 64 - 3 * G::HT; hrow += 3;
             if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
         });
@@ -167,6 +195,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
     // round r of the image in flight: zero what is padding, split, write to image buffer `buf`
     auto convert_store = [&](auto r_, bool all_in, unsigned mask, int chunk, int buf) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
+        asm volatile("" : "+v"(gin[r]));                       // (stays behind the wait that made it valid)
         f32x4 x = gin[r];
         const bool whole = all_in && (chunk + 1) * G::KC <= a.cin_phys;
         if (!whole) {
@@ -191,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
     // one tap of this half's filters -> ring slot
     auto dma_f = [&](const char* src, int slot /* byte offset of the ring slot */, int cnt) DCSCN_INL {
         const int pieces = cnt > 0 ? 2 * cnt : 1;
+        if constexpr (C3E_ABL & 1) return;
         static_for<0, F>([&](auto r_) DCSCN_INL {
             constexpr int r = decltype(r_)::value;
             const int piece = (w4 + 4 * r) % pieces;
@@ -207,8 +237,12 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         return w.f_base + (size_t)idx * tap_stride;
     };
 
-    auto run = [&](auto cnt_c) DCSCN_INL {
+    auto run = [&](auto cnt_c, auto half_c) DCSCN_INL {
     constexpr int CNT = decltype(cnt_c)::value;                // channel tiles of THIS half
+    constexpr int HALF = decltype(half_c)::value;
+    // one barrier per tap: half 0 keeps the one behind its compute phase, half 1 the one behind its load phase
+    constexpr bool BAR_L = !C3E_SB || HALF == 1, BAR_C = !C3E_SB || HALF == 0;
+    constexpr bool DMA_LATE = C3E_SB && HALF == 1;             // half 1 issues a tap's DMA behind the barrier (its target slot is read until then)
     // ---- first item ----
     Unit cur, nxt;
     int id = blockIdx.x;
@@ -222,13 +256,20 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
     dma_f(tap_src(cur, nxt, 0), sl0, CNT);
     dma_f(tap_src(cur, nxt, 1), sl1, CNT);
     load_in(cur.a_base, cur.ok_mask, 0);
-    static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, cur.all_in, cur.ok_mask, 0, 0); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, cur.all_in, cur.ok_mask, 0, 0); });
     c3p_barrier();
-    if (half == 1) c3p_barrier();                              // half 1 runs one phase behind half 0
+    if (!C3E_SB && half == 1) c3p_barrier();                   // half 1 runs one phase behind half 0
+    if (C3E_PRIO && half == C3E_PRIO - 1) asm volatile("s_setprio %0" :: "n"(C3E_PRIO_LEVEL));
 
     f32x4 acc[4][NT];
     h8 xh[4], xl[4], wa[NB], wb[NB];                           // B rows (hi, lo), A fragments (wl, wh) in a ring of PFD + 1 tiles
+    if constexpr (C3E_ABL != 0) {                              // finite operands for the ablation builds (non-finite ones slow the MFMAs down)
+        u32x4 z = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        asm volatile("" : "+v"(z));
+        static_for<0, 4>([&](auto m_) DCSCN_INL { xh[decltype(m_)::value] = xl[decltype(m_)::value] = __builtin_bit_cast(h8, z); });
+        static_for<0, NB>([&](auto m_) DCSCN_INL { wa[decltype(m_)::value] = wb[decltype(m_)::value] = __builtin_bit_cast(h8, z); });
+    }
     bool pending = false;                                      // an epilogue is owed (previous item)
     int parity = 0;
     // epilogue state of the previous item (its accumulators are still in acc until the first compute phase of the next item)
@@ -325,13 +366,17 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         pending = false;
         if constexpr (DBG == 1) { pr_epi += __builtin_readcyclecounter() - pr_a; ++pr_items; }
     };
-    auto phase_barrier = [&](long long& acc_wait) DCSCN_INL {
+    auto phase_barrier = [&](auto on_c, long long& acc_wait) DCSCN_INL {
         if constexpr (DBG == 1) pr_b = __builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);                     // MFMAs have no memory effect: without this the scheduler moves some across the barrier
-        c3p_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(on_c)::value) {
+            c3p_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (DBG == 1) acc_wait += __builtin_readcyclecounter() - pr_b;
     };
+    constexpr std::integral_constant<bool, BAR_L> bar_l{};
+    constexpr std::integral_constant<bool, BAR_C> bar_c{};
 
     while (true) {
         // bias / slopes of this item's tiles (the previous item's epilogue reads the other parity)
@@ -369,19 +414,21 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     const int hx = (l & 15) + kx;
                     b_hi = img_off + (4 * w4 * G::HT + hx) * G::PIX_BYTES + c3h_unit(hx, l >> 4, 0) * 16;
                 }
+                if constexpr (!(C3E_ABL & 16))
                 static_for<(ky == 0 ? 0 : 3), 4>([&](auto m_) DCSCN_INL {
                     constexpr int row = ky + decltype(m_)::value;
                     xh[row & 3] = *reinterpret_cast<const h8*>(smem + b_hi + row * G::ROW_BYTES);
                     xl[row & 3] = *reinterpret_cast<const h8*>(smem + (b_hi ^ 16) + row * G::ROW_BYTES);
                 });
                 const char* fs = smem + (step % 3 == 0 ? sl0 : step % 3 == 1 ? sl1 : sl2) + a_lane;
+                if constexpr (!(C3E_ABL & 4))
                 static_for<0, PFD>([&](auto p_) DCSCN_INL {
                     constexpr int p = decltype(p_)::value;
                     wb[p] = *reinterpret_cast<const h8*>(fs + (2 * p) * 1024);       // (tiles past the half's last: stale bytes of its own slot, never used)
                     wa[p] = *reinterpret_cast<const h8*>(fs + (2 * p + 1) * 1024);
                 });
-                if constexpr (step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>();        // the pieces issued in the previous load phase
-                {   // the tap two steps ahead: of this chunk, of the next one, of the packed tail, or of the next item
+                if constexpr (!C3E_SB) { if constexpr (step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>(); }   // the pieces issued in the previous load phase
+                auto dma_ahead = [&]() DCSCN_INL {   // the tap two steps ahead: of this chunk, of the next one, of the packed tail, or of the next item
                     constexpr int step2 = (step + 2) % 9;
                     constexpr int ptap2 = (step2 % 3) * 3 + step2 / 3;
                     const char* src;
@@ -390,14 +437,18 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                              : octs      ? cur.f_base + (size_t)(n_main * 9 + step2) * tap_stride
                                          : nxt.f_base + (size_t)ptap2 * tap_stride;
                     dma_f(src, (step + 2) % 3 == 0 ? sl0 : (step + 2) % 3 == 1 ? sl1 : sl2, CNT);
-                }
-                if constexpr (step == 0) load_in(li_base, li_ok, lchunk);
-                if constexpr (step >= 3) convert_store(std::integral_constant<int, step - 3>{}, li_all_in, li_ok, lchunk, ibuf ^ 1);
+                };
+                if constexpr (!DMA_LATE) dma_ahead();
+                if constexpr (step == 0 && !(C3E_ABL & 2)) load_in(li_base, li_ok, lchunk);
+                if constexpr (step >= 3 && !(C3E_ABL & 2)) convert_store(std::integral_constant<int, step - 3>{}, li_all_in, li_ok, lchunk, ibuf ^ 1);
                 if constexpr (step == 0) { if (chunk == 0 && pending) epilogue(); }
+                // half 1, one barrier per tap: the next tap's pieces were issued behind the previous barrier; only this step's image loads are younger
+                if constexpr (DMA_LATE) { if constexpr (step == 0) c3p_wait_vm<L>(); else c3p_wait_vm<0>(); }
                 if constexpr (DBG == 1) pr_load += __builtin_readcyclecounter() - pr_a;
-                phase_barrier(pr_bl);
+                phase_barrier(bar_l, pr_bl);
                 // ================= COMPUTE phase =================
                 if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
+                if constexpr (DMA_LATE) { dma_ahead(); __builtin_amdgcn_sched_barrier(0); }
                 if constexpr (step == 0) {
                     if (chunk == 0)
                         static_for<0, 4>([&](auto m_) DCSCN_INL {
@@ -408,19 +459,28 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     constexpr int CNT = decltype(cnt_c)::value;
                     static_for<0, CNT>([&](auto n_) DCSCN_INL {
                         constexpr int n = decltype(n_)::value;
-                        if constexpr (n + PFD < CNT) {
+                        if constexpr (n + PFD < CNT && !(C3E_ABL & 4)) {
                             wb[(n + PFD) % NB] = *reinterpret_cast<const h8*>(fs + (2 * (n + PFD)) * 1024);
                             wa[(n + PFD) % NB] = *reinterpret_cast<const h8*>(fs + (2 * (n + PFD) + 1) * 1024);
                         }
+                        if constexpr (C3E_ABL & 8) {
+                            asm volatile("" :: "v"(wa[n % NB]), "v"(wb[n % NB]));
+                            asm volatile("" :: "v"(xh[0]), "v"(xl[0]), "v"(xh[1]), "v"(xl[1]));
+                            asm volatile("" :: "v"(xh[2]), "v"(xl[2]), "v"(xh[3]), "v"(xl[3]));
+                        } else {
                         static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[n % NB], xh[(ky + m) & 3], acc[m][n], 0, 0, 0); });
                         static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[n % NB], xl[(ky + m) & 3], acc[m][n], 0, 0, 0); });
                         static_for<0, 4>([&](auto m_) DCSCN_INL { constexpr int m = decltype(m_)::value; acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[n % NB], xh[(ky + m) & 3], acc[m][n], 0, 0, 0); });
+                        }
                         __builtin_amdgcn_sched_barrier(0);     // a tile's reads and MFMAs stay where they are (hoisted, the reads of all tiles cost 40 more registers)
                     });
                 };
                 mfmas(std::integral_constant<int, CNT>{});
+                // half 0, one barrier per tap: the NEXT tap's pieces (issued in the previous load phase) must have landed before the barrier;
+                // younger than them: this load phase's F pieces, and the six image loads of a step 0 during the two steps after it
+                if constexpr (C3E_SB && HALF == 0) { if constexpr (step <= 1) c3p_wait_vm<F + L>(); else c3p_wait_vm<F>(); }
                 if constexpr (DBG == 1) pr_comp += __builtin_readcyclecounter() - pr_a;
-                phase_barrier(pr_bc);
+                phase_barrier(bar_c, pr_bc);
                 ++tt;
             });
             ibuf ^= 1;
@@ -433,10 +493,13 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
             auto tail_step = [&](int step, auto first_c) DCSCN_INL {
                 constexpr bool FIRST = decltype(first_c)::value;
                 if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
-                if (!FIRST && step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>();
-                dma_f(tap_src(cur, nxt, tt + 2), sl2, CNT);
-                if constexpr (FIRST) load_in(nxt.a_base, nxt.ok_mask, 0);
-                if (!FIRST && step == 2) static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, nxt.all_in, nxt.ok_mask, 0, ibuf ^ 1); });
+                if constexpr (!C3E_SB) { if (!FIRST && step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>(); }
+                if (!FIRST && step == 2 && !(C3E_ABL & 2)) {
+                    if constexpr (C3E_SB && HALF == 0) c3p_wait_vm<F>();      // the image loads of tail step 0 (younger: step 1's pieces)
+                    static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, nxt.all_in, nxt.ok_mask, 0, ibuf ^ 1); });
+                }
+                if constexpr (!DMA_LATE) dma_f(tap_src(cur, nxt, tt + 2), sl2, CNT);
+                if constexpr (FIRST && !(C3E_ABL & 2)) load_in(nxt.a_base, nxt.ok_mask, 0);
                 const int pair = 4 * step + (l >> 4);
                 int tap = octs == 1 ? pair : octs == 2 ? pair >> 1 : (pair * 11) >> 5;
                 const int oct = pair - tap * octs;
@@ -455,9 +518,11 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     wb[p] = *reinterpret_cast<const h8*>(fs + (2 * p) * 1024);       // (tiles past the half's last: stale bytes of its own slot, never used)
                     wa[p] = *reinterpret_cast<const h8*>(fs + (2 * p + 1) * 1024);
                 });
+                if constexpr (DMA_LATE) { if constexpr (FIRST) c3p_wait_vm<L>(); else c3p_wait_vm<0>(); }
                 if constexpr (DBG == 1) pr_load += __builtin_readcyclecounter() - pr_a;
-                phase_barrier(pr_bl);
+                phase_barrier(bar_l, pr_bl);
                 if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
+                if constexpr (DMA_LATE) { dma_f(tap_src(cur, nxt, tt + 2), sl2, CNT); __builtin_amdgcn_sched_barrier(0); }
                 auto mfmas = [&](auto cnt_c) DCSCN_INL {
                     constexpr int CNT = decltype(cnt_c)::value;
                     static_for<0, CNT>([&](auto n_) DCSCN_INL {
@@ -473,8 +538,9 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     });
                 };
                 mfmas(std::integral_constant<int, CNT>{});
+                if constexpr (C3E_SB && HALF == 0) { if (FIRST || step == 1) c3p_wait_vm<F + L>(); else c3p_wait_vm<F>(); }
                 if constexpr (DBG == 1) pr_comp += __builtin_readcyclecounter() - pr_a;
-                phase_barrier(pr_bc);
+                phase_barrier(bar_c, pr_bc);
                 ++tt;
                 { const int t = sl0; sl0 = sl1; sl1 = sl2; sl2 = t; }   // the ring moves on by one slot per tail step
             };
@@ -492,10 +558,10 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         decode(id + (int)gridDim.x, nxt);
     }
     epilogue();
-    if (half == 0) c3p_barrier();                              // pairs with half 1's extra barrier at the start
+    if (!C3E_SB && half == 0) c3p_barrier();                   // pairs with half 1's extra barrier at the start
     };
-    if (half == 0) run(std::integral_constant<int, NT>{});
-    else run(std::integral_constant<int, C1>{});
+    if (half == 0) run(std::integral_constant<int, NT>{}, std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, C1>{}, std::integral_constant<int, 1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // no LDS-DMA may land after the workgroup has given its LDS back
     if constexpr (DBG == 1) {
         if (lane == 0 && a.srctab) {

@@ -118,7 +118,11 @@ def _encode_and_write(filename, image, mode):
 
 
 def save_image(filename, image, print_console=True):
-    """Cast to uint8 the way the reference does (plain ``astype``, no rounding: utilty.py:113-130)."""
+    """Cast to uint8 the way the reference does (plain ``astype``, no rounding: utilty.py:113-130).
+
+    Synchronous, like the reference's -- except inside a ``deferred_saves()`` block, where the PNG is encoded and written on a
+    worker thread and the block's exit waits for it (model.do_for_file / do_for_evaluate_with_output write up to seven images per file).
+    """
     global _save_pool
     if len(image.shape) >= 3 and image.shape[2] == 1:
         image = image.reshape(image.shape[0], image.shape[1])
@@ -128,30 +132,26 @@ def save_image(filename, image, print_console=True):
     with np.errstate(invalid="ignore"):
         image = np.ascontiguousarray(image.astype(np.uint8))
     mode = "RGB" if image.ndim == 3 and image.shape[2] == 3 else None
-    if _save_pool is None:
-        import atexit
-        from concurrent.futures import ThreadPoolExecutor
-        _save_pool = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
-        atexit.register(flush_saves)
-    _save_pending.append(_save_pool.submit(_encode_and_write, filename, image, mode))
+    if _save_defer > 0:
+        if _save_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _save_pool = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+        _save_pending.append(_save_pool.submit(_encode_and_write, filename, image, mode))
+    else:
+        _encode_and_write(filename, image, mode)
     if print_console:
         print("Saved [%s]" % filename)
 
 
 def flush_saves():
-    """Wait until every image handed to save_image is on disk (re-raises the first write error)."""
+    """Wait until every image handed to save_image inside a deferred_saves() block is on disk (re-raises the first write error)."""
     pending, _save_pending[:] = list(_save_pending), []
     for f in pending:
         f.result()
 
 
-def flush_saves_unless_deferred():
-    if _save_defer == 0:
-        flush_saves()
-
-
 class deferred_saves(object):
-    """``with deferred_saves():`` -- save_image calls inside return at once, the block's exit waits for all of them."""
+    """``with deferred_saves():`` -- save_image calls inside return at once, the (outermost) block's exit waits for all of them."""
     def __enter__(self):
         global _save_defer
         _save_defer += 1
@@ -163,6 +163,17 @@ class deferred_saves(object):
         if _save_defer == 0:
             flush_saves()
         return False
+
+
+def with_deferred_saves(fn):
+    """Decorator: the function's save_image calls run on worker threads; it returns when its files are on disk."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with deferred_saves():
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 # ---- colour -------------------------------------------------------------------------------------

@@ -334,6 +334,7 @@ class SuperResolution:
         """Extension: [n, h, w, 1] + [n, s*h, s*w, 1] float32 -> [n, s*h, s*w, 1] in one device pass."""
         return self._ready_engine().forward(lr_batch, bicubic_batch)
 
+    @util.with_deferred_saves                                # the PNGs are encoded on worker threads; on disk when this returns
     def do_for_file(self, file_path, output_folder="output"):
         """sr.py's work (DCSCN.py:588-614): writes the original, bicubic and SR images."""
         org_image = util.load_image(file_path)
@@ -364,7 +365,6 @@ class SuperResolution:
             util.save_image(output_folder + filename + "_bicubic_y" + extension, scaled_image)
             image = self.do(org_image)
         util.save_image(output_folder + filename + "_result" + extension, image)
-        util.flush_saves_unless_deferred()                  # the PNGs are encoded on worker threads (imaging.save_image)
 
     def _device_colour_path(self, image):
         """uint8 RGB through the device colour / bicubic kernels: they reproduce the float64 numpy colour math and
@@ -446,6 +446,7 @@ class SuperResolution:
                 print("[%s] PSNR:%s, SSIM:%s" % (path, psnr, ssim))
         return [(psnr, ssim, per_file) for psnr, ssim in values]
 
+    @util.with_deferred_saves
     def do_for_evaluate_with_output(self, file_path, output_directory, print_console=False):
         """As above, also writing the result images (DCSCN.py:616-670)."""
         filename, extension = os.path.splitext(file_path)
@@ -485,10 +486,8 @@ class SuperResolution:
             util.save_image(output_directory + file_path, true_image)
             util.save_image(output_directory + filename + "_result" + extension, output_image)
         else:
-            util.flush_saves_unless_deferred()
             return None, None
 
-        util.flush_saves_unless_deferred()                  # the PNGs are encoded on worker threads (imaging.save_image)
         if print_console:
             print("[%s] PSNR:%f, SSIM:%f" % (filename, psnr, ssim))
         return psnr, ssim
