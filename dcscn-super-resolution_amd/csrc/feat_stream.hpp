@@ -37,7 +37,8 @@
 #include "conv_igemm.hpp"
 
 #ifndef STREAM_ABL
-#define STREAM_ABL 0      // tools/stream_abl.sh: timing-only builds with one cost removed (results wrong by design)
+#define STREAM_ABL 0      // tools/stream_abl.sh: timing-only builds with one cost removed (results wrong by design); 1 = no MFMA in the
+                          // separable convs (4 VALU FMAs per tile instead), 15 = no MFMA anywhere (A1 || B1 waves too): a bound for ANY faster matrix instruction
 #endif
 
 namespace dcscn {
@@ -278,7 +279,7 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], const f32x4 (
                 const float bv = K::pick(d[m], s, q);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    if (STREAM_ABL == 1) { if (s == 0) acc[m][n] = (ch == 0 ? init[n] : acc[m][n]) + d[m] * wp[n]; }
+                    if (STREAM_ABL == 1 || STREAM_ABL == 15) { if (s == 0) acc[m][n] = (ch == 0 ? init[n] : acc[m][n]) + d[m] * wp[n]; }
                     else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[n][s], bv, ch == 0 && s == 0 ? init[n] : acc[m][n], 0, 0, 0);
                 }
             }
@@ -418,8 +419,11 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
                             if (k < steps) {
 #pragma unroll
                                 for (int m = 0; m < kStreamMT; ++m) {
+                                    if (STREAM_ABL == 15) { if (k == 0) { acc[p][m][0] += w0 * xv[m]; acc[p][m][1] += w1 * xv[m]; } }
+                                    else {
                                     acc[p][m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[k], xv[m][k], acc[p][m][0], 0, 0, 0);
                                     acc[p][m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[k], xv[m][k], acc[p][m][1], 0, 0, 0);
+                                    }
                                 }
                             }
                     }

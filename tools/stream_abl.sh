@@ -7,7 +7,7 @@ P=$R/dcscn-super-resolution_amd
 mkdir -p $R/tools/abl
 if [ "$1" = build ]; then
   for n in ${ABLS:-1 2 3 4}; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DSTREAM_ABL=$n -I $R/include -c $P/csrc/feat_stream.hip -o $R/tools/abl/fs$n.o || exit 1
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops -DSTREAM_ABL=$n -I $R/include -c $P/csrc/feat_stream.hip -o $R/tools/abl/fs$n.o || exit 1
     objs=$(ls $P/build/*.o | grep -v feat_stream.o)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $R/tools/abl/fs$n.o -o $R/tools/abl/libdcscn_abl$n.so || exit 1
   done
