@@ -304,7 +304,7 @@ def main():
         lr_pixels = n * PATCH * PATCH                         # this rank's
         global_lr_pixels = global_patches * PATCH * PATCH
         # dominant kernel: the Winograd 3x3 launches (CNN2..12, B2, and Up-PS in the layer-by-layer graph)
-        C3H = ("conv3_h", "conv3_h8")           # the split16 3x3 kernels: 4-wave workgroups / 8-wave ping-pong workgroups sharing the input tile
+        C3H = ("conv3_h", "conv3_h8")           # the split16 3x3 kernels: 4-wave workgroups / persistent 8-wave workgroups sharing the input tile
         dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino2") + C3H
                and o["kernel_size"] == 3 and o["out_channels"] > 1]
         dom_kernels = sorted({o["kernel"] for o, _ in dom})
