@@ -63,8 +63,12 @@ struct C3HGeom {
     static constexpr int LDS_BYTES = BA_BASE + NT * 128;
 };
 
-// position (16-byte unit) of channel group kq, piece `part` (0 hi, 1 lo) inside the record of halo column hx
-__host__ __device__ constexpr int c3h_unit(int hx, int kq, int part) { return (((kq + ((hx >> 1) & 3)) & 3) << 1) | (part ^ (kq & 1)); }
+// position (16-byte unit) of channel group kq, piece `part` (0 hi, 1 lo) inside the record of halo column hx.  Reads (ds_read_b128, 64
+// banks = two records): the 16 lanes of a lane group see 16 distinct (column parity, unit) pairs for every tap column.  Writes
+// (ds_write_b64, 32 banks = ONE record, 16 lanes = two neighbouring columns x 8 channel quads): the column parity in the low bit puts the
+// hi pieces of an odd column where the even column has its lo pieces, so the two columns of a store fill one record's worth of banks
+// exactly once (r03 had them on the same banks: 2-way conflicts on every store of the image).
+__host__ __device__ constexpr int c3h_unit(int hx, int kq, int part) { return (((kq + ((hx >> 1) & 3)) & 3) << 1) | ((part ^ kq ^ hx) & 1); }
 
 // ABL (tuner only, tools/h16_tune.hip; results are wrong by design): 0 shipped; 1 no convert + write of the input image after the
 // first chunk; 2 nor its global loads; 3 no filter staging after the first tap; 4 no per-tap barrier; 5 one MFMA product of three;
@@ -163,8 +167,7 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
             constexpr int r = decltype(r_)::value;
             const int hp = r * 32 + hp0;
             const int kq = cq >> 1;
-            const int unit = (((kq + ((hcol >> 1) & 3)) & 3) << 1) | (kq & 1);
-            const int off = hp * G::PIX_BYTES + unit * 16 + (cq & 1) * 8;
+            const int off = hp * G::PIX_BYTES + c3h_unit(hcol, kq, 0) * 16 + (cq & 1) * 8;
             const u32x4 v = __builtin_bit_cast(u32x4, gin[r]);
             if (r < G::IN_ROUNDS - 1 || hp < G::HP) {
                 *reinterpret_cast<u32x2*>(smem + off) = u32x2{v.x, v.y};

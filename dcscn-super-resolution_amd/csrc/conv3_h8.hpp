@@ -210,8 +210,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         const int hp = r * 64 + hp0;
         const int hcol = hp % G::HT;
         const int kq = cq >> 1;
-        const int unit = (((kq + ((hcol >> 1) & 3)) & 3) << 1) | (kq & 1);
-        const int off = buf * G::IN_BYTES + hp * G::PIX_BYTES + unit * 16 + (cq & 1) * 8;
+        const int off = buf * G::IN_BYTES + hp * G::PIX_BYTES + c3h_unit(hcol, kq, 0) * 16 + (cq & 1) * 8;
         if (r < L - 1 || hp < G::HP) {
             *reinterpret_cast<u32x2*>(smem + off) = hu;
             *reinterpret_cast<u32x2*>(smem + (off ^ 16)) = lu;

@@ -121,8 +121,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
             constexpr int r = decltype(r_)::value;
             const int hp = r * 32 + hp0;
             const int kq = cq >> 1;
-            const int unit = (((kq + ((hcol >> 1) & 3)) & 3) << 1) | (kq & 1);
-            const int off = hp * G::PIX_BYTES + unit * 16 + (cq & 1) * 8;
+            const int off = hp * G::PIX_BYTES + c3h_unit(hcol, kq, 0) * 16 + (cq & 1) * 8;
             const u32x4 v = __builtin_bit_cast(u32x4, gin[r]);
             if (r < G::IN_ROUNDS - 1 || hp < G::HP) {
                 *reinterpret_cast<u32x2*>(smem + off) = u32x2{v.x, v.y};

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv3_hp(const ConvArgs a) {
             constexpr int r = decltype(r_)::value;
             const int hp = r * 32 + hp0;
             const int kq = cq >> 1;
-            const int unit = (((kq + ((hcol >> 1) & 3)) & 3) << 1) | (kq & 1);
+            const int unit = c3h_unit(hcol, kq, 0);
             const int off = hp * G::PIX_BYTES + unit * 16 + (cq & 1) * 8;
             const u32x4 v = __builtin_bit_cast(u32x4, gin[r]);
             if (r < L - 1 || hp < G::HP) {
