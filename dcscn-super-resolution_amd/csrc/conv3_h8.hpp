@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
     const int n_main = octs ? n_chunks - 1 : n_chunks;
     const int n_tail = (9 * octs + 3) >> 2;
     const int t_total = n_main * 9 + n_tail;                   // taps (MFMA steps) of an item
-    const bool fastable = a.ps == 1 && a.res == nullptr && (a.act == ACT_ALPHA || a.act == ACT_NONE);
+    const bool fastable = a.ps == 1 && a.res == nullptr && (a.act == ACT_ALPHA || a.act == ACT_NONE) && (a.split & 15) == 0;   // (two destinations: split on a tile boundary)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned f_off = (unsigned)(lane * 16);
     const int cq = tid & 7;
