@@ -125,7 +125,7 @@ inline int c3h_tail_steps(int octs) { return (9 * octs + 3) / 4; }
 hipError_t c3h_init_kernels();
 hipError_t c3h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
 // conv3_h8 (conv3_h8.hpp): conv3_h's launches with exactly two channel groups as ONE persistent 8-wave workgroup per CU -- the pixel
-// tile's input image staged once for both groups, the halves in ping-pong; same wpack16 image, same arguments, bit-identical results
+// tile's input image staged once for both groups, the halves running their load and compute parts in opposite order between one barrier per tap; same wpack16 image, same arguments, bit-identical results
 hipError_t c3e_init_kernels();
 bool c3e_eligible(int nt, const ConvArgs& a, int n_groups);
 hipError_t c3e_launch(int nt, const ConvArgs& a, int n_groups, int n_cus, hipStream_t stream);

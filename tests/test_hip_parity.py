@@ -311,7 +311,7 @@ def test_do_with_max_value(oracle, tmp_path, max_value, split16, monkeypatch):
 @pytest.mark.parametrize("name", ["L12_F196to48_x2", "L12_F196to48_x4", "wide-3"])
 def test_conv3_h8_is_bit_identical_to_conv3_h(oracle, name):
     """Layers with two channel groups run on conv3_h8 (one persistent 8-wave workgroup per CU, the pixel tile's input staged once for
-    both groups, halves in ping-pong); the option conv3_h8 = 0 sends them to conv3_h.  Same arithmetic in the same order: same bits,
+    both groups, the halves running load and compute in opposite order); the option conv3_h8 = 0 sends them to conv3_h.  Same arithmetic in the same order: same bits,
     on ragged sizes (image-edge tiles take conv3_h8's general epilogue) and with more items than workgroups."""
     from dcscn_amd import engine
     flags = CONFIGS[name] if name in CONFIGS else dict(layers=3, filters=176, min_filters=112, filters_decay_gamma=1.0, nin_filters=48, nin_filters2=24)
