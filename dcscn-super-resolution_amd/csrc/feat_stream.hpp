@@ -38,7 +38,12 @@
 
 #ifndef STREAM_ABL
 #define STREAM_ABL 0      // tools/stream_abl.sh: timing-only builds with one cost removed (results wrong by design); 1 = no MFMA in the
-                          // separable convs (4 VALU FMAs per tile instead), 15 = no MFMA anywhere (A1 || B1 waves too): a bound for ANY faster matrix instruction
+                          // separable convs (4 VALU FMAs per tile instead), 15 = no MFMA anywhere (A1 || B1 waves too): a bound for ANY faster matrix instruction,
+                          // 16 = PROJECTION of a split16 variant: per two 16-channel chunks the 8 NT v_mfma_f32_16x16x4_f32 are replaced by the hi / lo
+                          // split of the B values (12 VALU per pixel tile) and 3 NT v_mfma_f32_16x16x32_f16 on stand-in A operands (finite bit patterns)
+#endif
+#if STREAM_ABL == 16
+#include "split16.hpp"
 #endif
 
 namespace dcscn {
@@ -222,6 +227,9 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], const f32x4 (
                                              int q, int lane) {
     constexpr int CH = (QUADS + 3) / 4;
     constexpr unsigned PX = (unsigned)(QUADS | 1) * 16u;
+#if STREAM_ABL == 16
+    f32x4 dkeep[MT];
+#endif
     static_for<0, CH>([&](auto ch_) DCSCN_INL {
         constexpr int ch = decltype(ch_)::value;
         constexpr int QL = ch == CH - 1 ? QUADS - 4 * (CH - 1) : 4;
@@ -272,6 +280,28 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], const f32x4 (
             for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(d[m]));
         }
         // (lanes of a missing quad hold the depthwise of a real one: finite, times zero filter rows)
+#if STREAM_ABL == 16
+        if constexpr ((ch & 1) == 0 && ch != CH - 1) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) dkeep[m] = d[m];
+        } else {
+            const float m1 = opaque_minus_one();
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                h8 bh, bl;
+                if constexpr ((ch & 1) != 0) split8(dkeep[m], d[m], m1, bh, bl); else split8(d[m], d[m], m1, bh, bl);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const u32x4 wu = __builtin_bit_cast(u32x4, wp[n]) & 0x3fff3fffu;      // a finite f16 pattern (timing only)
+                    const h8 ah = __builtin_bit_cast(h8, wu);
+                    f32x4 c0 = ch <= 1 ? init[n] : acc[m][n];
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c0, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c0, 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c0, 0, 0, 0);
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int s = 0; s < K::STEPS; ++s)
 #pragma unroll
@@ -283,6 +313,7 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], const f32x4 (
                     else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[n][s], bv, ch == 0 && s == 0 ? init[n] : acc[m][n], 0, 0, 0);
                 }
             }
+#endif
     });
 }
 
@@ -390,6 +421,11 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
                 const StreamRow ri = stream_row(a, j0, cur[p], g);
                 if (!ri.zero) {
                     const unsigned rowb = lds0 + s.ring.off + ((unsigned)(g % 3) * kStreamRowPx + 3 * j + 1) * (unsigned)s.ring.units * 16u;
+#if STREAM_ABL == 16
+                    f32x4 xkeep[kStreamMT];
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) xkeep[m] = f32x4{1.0f, 2.0f, 3.0f, 4.0f};
+#endif
 #pragma unroll 1
                     for (int ch = 0; ch < s.chunks; ++ch) {
                         // StreamChunk<ql> with a run-time ql (one code path: this role is short of registers, not of VALU slots)
@@ -414,6 +450,28 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
                                 xv[m].y = e1;
                             }
                         }
+#if STREAM_ABL == 16
+                        if ((ch & 1) == 0 && ch != s.chunks - 1) {
+#pragma unroll
+                            for (int m = 0; m < kStreamMT; ++m) xkeep[m] = xv[m];
+                        } else {
+                            const float m1 = opaque_minus_one();
+                            const h8 a0 = __builtin_bit_cast(h8, __builtin_bit_cast(u32x4, w0) & 0x3fff3fffu);
+                            const h8 a1 = __builtin_bit_cast(h8, __builtin_bit_cast(u32x4, w1) & 0x3fff3fffu);
+#pragma unroll
+                            for (int m = 0; m < kStreamMT; ++m) {
+                                h8 bh, bl;
+                                split8(xkeep[m], xv[m], m1, bh, bl);
+                                f32x4 c0 = acc[p][m][0], c1 = acc[p][m][1];
+                                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh, c0, 0, 0, 0);
+                                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, c1, 0, 0, 0);
+                                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl, c0, 0, 0, 0);
+                                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, c1, 0, 0, 0);
+                                acc[p][m][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh, c0, 0, 0, 0);
+                                acc[p][m][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, c1, 0, 0, 0);
+                            }
+                        }
+#else
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (k < steps) {
@@ -426,6 +484,7 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
                                     }
                                 }
                             }
+#endif
                     }
                 }
                 if (last) {
