@@ -152,7 +152,8 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * the network's receptive-field radius, run as a batch and stitched -- "spatial_tiling" 0 disables that and
  * lets the allocation fail instead), "profile" (1: time every launch with HIP events, read back with dcscn_get_profile),
  * "winograd" (default 1; before dcscn_finalize only: 0 keeps every 3x3 conv on the direct
- * implicit-GEMM kernel instead of the Winograd F(2x2,3x3) kernel),
+ * implicit-GEMM kernel instead of the Winograd F(2x2,3x3) kernel), "nin_gemm" (default 1; before dcscn_finalize only: 0 sends
+ * the wide 1x1 convs -- A1 || B1 over the skip-concat -- to the generic implicit-GEMM kernel instead of conv_nin_h / conv_nin),
  * "fold_linear_tail" (default 1; before dcscn_finalize only): the last pixel-shuffler conv, depth_to_space and the last
  * reconstruction conv -- all linear, no activator between them, DCSCN.py:293-323 -- run as ONE 5x5 conv of the
  * low-resolution map with per-phase / per-border kernels composed in float64 from the checkpoint tensors; the same

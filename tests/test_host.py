@@ -361,3 +361,17 @@ def test_library_has_no_packed_f32_instructions(tmp_path):
         mfma += dis.count("v_mfma_f32_16x16x32_f16")
     assert mfma > 1000, "disassembly did not find the kernels"
     assert packed == 0, "%d packed-f32 VALU instructions in libdcscn_hip.so" % packed
+
+
+def test_every_option_of_the_library_is_documented():
+    """Each key dcscn_set_option accepts (csrc/api.hip) is described in include/dcscn.h and listed in INTEGRATION.md."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = [d for d in os.listdir(root) if d.endswith("_amd") and os.path.isdir(os.path.join(root, d))][0]
+    api = open(os.path.join(root, pkg, "csrc", "api.hip")).read()
+    keys = sorted(set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', api)))
+    assert len(keys) >= 10
+    header = open(os.path.join(root, "include", "dcscn.h")).read()
+    integration = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = [k for k in keys if '"%s"' % k not in header or "`%s`" % k not in integration]
+    assert not missing, "undocumented options: %s" % missing
