@@ -56,6 +56,9 @@ __global__ void fill_act(float* p, size_t n, unsigned seed) {
         if (sel == 0) v *= 8.0f;            // up to ~1400
         else if (sel < 8) v *= 1e-4f;       // tiny values: lo pieces go subnormal
         p[i] = v > 0.0f ? v : 0.2f * v;
+#ifdef H16_CONST_ACT                        // every activation the same value: what the clock does when the operands do not toggle
+        p[i] = 1.0f;
+#endif
     }
 }
 
