@@ -47,6 +47,7 @@
 //     step 0, vmcnt(0) otherwise.
 #pragma once
 #include "conv3_h.hpp"
+#include "p16.hpp"
 
 namespace dcscn {
 
@@ -65,12 +66,13 @@ struct C3EGeom {
     static constexpr int THREADS = 512;
     static constexpr int KC = 32, TH = 16, TW = 16, HT = 18, HP = HT * HT;
     static constexpr int PIX_BYTES = 128, ROW_BYTES = HT * PIX_BYTES, IN_BYTES = HP * PIX_BYTES;   // 41472
+    static constexpr int IN_BUF = 41 * 1024;                      // an image buffer: 41 DMA pieces of 1 KB (P16 staging; the last piece is half padding)
     static constexpr int IN_ITEMS = HP * 8;
     static constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;                            // 6 (the last one: 32 items)
     static constexpr int F_TAP_BYTES = NT * 2048;                 // one tap of one half: [n][hi | lo][64 lanes][16 bytes]
     static constexpr int F_ROUNDS = (2 * NT + 3) / 4;             // DMA instructions per wave and tap
     static constexpr int IMG = 0;                                 // two image buffers
-    static constexpr int F_BASE = 2 * IN_BYTES;                   // [half][slot]
+    static constexpr int F_BASE = 2 * IN_BUF;                     // [half][slot]
     static constexpr int BA_BASE = F_BASE + 2 * 3 * F_TAP_BYTES;  // [parity][half][bias | slopes]: NT * 128 bytes each
     static constexpr int LDS_BYTES = BA_BASE + 4 * NT * 128;
 };
@@ -97,9 +99,12 @@ struct C3EGeom {
 // LDS reads in front of every tile, and merging code variants cost 60 VGPRs in copies of the accumulators).
 // NTP = channel tiles per group in the filter image when that is a launch constant too (two-group layers: NTP = NT, every tap address an
 // immediate offset), 0 = args.nt_pack (tuner: one group split between the halves)
-template <int NT, int C1, int DBG = 0, int NTP = NT>
+// P16 = the input is a pre-split tensor (a.in16, p16.hpp) staged by LDS-DMA, and the destinations are P16 tensors too (the layers this
+// kernel runs feed split16 consumers only); false = float32 NHWC in and out, split in registers (r04)
+template <int NT, int C1, int DBG = 0, int NTP = NT, bool P16 = false>
 __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
     static_assert(C1 == NT || C1 == NT - 1, "half 1 takes as many tiles as half 0 or one fewer");
+    static_assert(!P16 || C3E_SB, "P16 staging is written for the one-barrier schedule");
     constexpr int PFD = C3E_PFD < NT ? C3E_PFD : (NT > 1 ? NT - 1 : 1), NB = PFD + 1;
     using G = C3EGeom<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem_c3e[];
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
     // ---- what this half does of an item: channel group g, its tiles [o, o + cnt) ----
     struct Unit {
         int valid, tile_id, img, y0, x0, g, o;
+        int pix0;                                              // P16: flat pixel index of the halo tile's origin (may be negative)
         bool all_in, full;
         const char* a_base;
         const char* f_base;
@@ -155,7 +161,8 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         u.y0 = ty * G::TH; u.x0 = tx * G::TW;
         u.all_in = u.y0 >= 1 && u.x0 >= 1 && u.y0 + G::TH + 1 <= H && u.x0 + G::TW + 1 <= W;
         u.full = u.y0 + G::TH <= H && u.x0 + G::TW <= W;
-        u.a_base = reinterpret_cast<const char*>(a.in + (size_t)u.img * H * W * a.in_stride + a.in_off + ((ptrdiff_t)(u.y0 - 1) * W + (u.x0 - 1)) * a.in_stride);
+        if constexpr (P16) { u.a_base = nullptr; u.pix0 = (u.img * H + u.y0 - 1) * W + u.x0 - 1; }
+        else { u.pix0 = 0; u.a_base = reinterpret_cast<const char*>(a.in + (size_t)u.img * H * W * a.in_stride + a.in_off + ((ptrdiff_t)(u.y0 - 1) * W + (u.x0 - 1)) * a.in_stride); }
         u.f_base = reinterpret_cast<const char*>(a.wpack16) + (size_t)u.g * n_chunks * 9 * tap_stride + (size_t)u.o * 2048;
         unsigned m = 0;
         int hp0 = tid >> 3;
@@ -164,7 +171,12 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         static_for<0, L>([&](auto r_) DCSCN_INL {
             constexpr int r = decltype(r_)::value;
             const int gy = u.y0 - 1 + hrow, gx = u.x0 - 1 + hcol;
-            const bool ok = r * 64 + hp0 < G::HP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            bool ok = r * 64 + hp0 < G::HP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if constexpr (P16 && r == L - 1) {                 // every wave fetches DMA piece 40 (halo pixels 320 + (lane >> 3)) of the image
+                const int hp = 320 + (hp0 & 7), hr = hp / G::HT, hc = hp - G::HT * hr;
+                const int qy = u.y0 - 1 + hr, qx = u.x0 - 1 + hc;
+                ok = hp < G::HP && qy >= 0 && qy < H && qx >= 0 && qx < W;
+            }
             m |= ok ? (1u << r) : 0u;
             hcol += 64 - 3 * G::HT; hrow += 3;
             if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
@@ -210,11 +222,31 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         const int hp = r * 64 + hp0;
         const int hcol = hp % G::HT;
         const int kq = cq >> 1;
-        const int off = buf * G::IN_BYTES + hp * G::PIX_BYTES + c3h_unit(hcol, kq, 0) * 16 + (cq & 1) * 8;
+        const int off = buf * G::IN_BUF + hp * G::PIX_BYTES + c3h_unit(hcol, kq, 0) * 16 + (cq & 1) * 8;
         if (r < L - 1 || hp < G::HP) {
             *reinterpret_cast<u32x2*>(smem + off) = hu;
             *reinterpret_cast<u32x2*>(smem + (off ^ 16)) = lu;
         }
+    };
+    // P16 staging: DMA piece r of this wave = 8 halo pixels x 8 units; lane (pixel, slot) fetches the unit c3h_unit puts at that slot.
+    // Out-of-image pixels and octets past the tensor's last come from the plane's zero record: every lane always issues.
+    auto img_piece = [&](auto r_, int pix0, unsigned mask, int chunk, int buf) DCSCN_INL {
+        constexpr int r = decltype(r_)::value;
+        const int rem = a.in16.octs - 4 * chunk;               // octets of this chunk (wave-uniform)
+        const int rec = rem >= 4 ? 128 : 32 * rem;
+        const char* base = a.in16.base + (long long)chunk * a.in16.plane;
+        int t8 = tid >> 3;
+        asm volatile("" : "+v"(t8));
+        const int hp = r < L - 1 ? r * 64 + t8 : 320 + (t8 & 7);
+        const int hrow = hp / G::HT, hcol = hp - G::HT * hrow;
+        const int s = lane & 7;
+        const int kq = ((s >> 1) - (hcol >> 1)) & 3;
+        const int part = (s ^ kq ^ hcol) & 1;
+        const bool ok = ((mask >> r) & 1u) && kq < rem;
+        const unsigned voff = ok ? (unsigned)(128 + (pix0 + hrow * W + hcol) * rec + (2 * kq + part) * 16) : (unsigned)(s * 16);
+        const int piece = r < L - 1 ? wave + 8 * r : 40;
+        if constexpr (C3E_ABL & 2) return;
+        glds16c(base, voff, lds0 + (unsigned)(buf * G::IN_BUF + piece * 1024));
     };
     // one tap of this half's filters -> ring slot
     auto dma_f = [&](const char* src, int slot /* byte offset of the ring slot */, int cnt) DCSCN_INL {
@@ -254,9 +286,14 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
     int sl0 = G::F_BASE + (half * 3 + 0) * G::F_TAP_BYTES, sl1 = G::F_BASE + (half * 3 + 1) * G::F_TAP_BYTES, sl2 = G::F_BASE + (half * 3 + 2) * G::F_TAP_BYTES;
     dma_f(tap_src(cur, nxt, 0), sl0, CNT);
     dma_f(tap_src(cur, nxt, 1), sl1, CNT);
-    load_in(cur.a_base, cur.ok_mask, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, cur.all_in, cur.ok_mask, 0, 0); });
+    if constexpr (P16) {
+        static_for<0, L>([&](auto r_) DCSCN_INL { img_piece(r_, cur.pix0, cur.ok_mask, 0, 0); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        load_in(cur.a_base, cur.ok_mask, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, cur.all_in, cur.ok_mask, 0, 0); });
+    }
     c3p_barrier();
     if (!C3E_SB && half == 1) c3p_barrier();                   // half 1 runs one phase behind half 0
     if (C3E_PRIO && half == C3E_PRIO - 1) asm volatile("s_setprio %0" :: "n"(C3E_PRIO_LEVEL));
@@ -285,6 +322,62 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         int le = lane;
         asm volatile("" : "+v"(le));
         const int lje = le & 15, lke = le >> 4;
+        if constexpr (P16) {
+            // P16 destinations (p16.hpp): every lane stores ONE 16-byte unit per accumulator tile -- unit lke of the tile's two octets of
+            // its pixel's record; one 64-bit base per tile, 32-bit lane offsets.  MASK: tiles that stick out of the image.
+            const h2 zero2 = p16_opaque_zero2();
+            auto finish = [&](auto act_c, auto mask_c) DCSCN_INL {
+                constexpr int ACT_C = decltype(act_c)::value;
+                constexpr bool MASK = decltype(mask_c)::value;
+                const bool col_ok = !MASK || e_x0 + lje < W;
+                static_for<0, CNT>([&](auto n_) DCSCN_INL {
+                    constexpr int n = decltype(n_)::value;
+                    const int c0 = cb16 + n * 16;
+                    const bool first = c0 < a.split;
+                    const P16Desc& od = first ? a.out0.p16 : a.out1.p16;
+                    const int oct0 = ((first ? a.out0.off : a.out1.off) + (first ? c0 : c0 - a.split)) >> 3;
+                    const int chunk = oct0 >> 2, rem = od.octs - 4 * chunk;
+                    const int rec = rem >= 4 ? 128 : 32 * rem;
+                    char* base = od.base + (long long)chunk * od.plane + 128 + (long long)((e_img * H + e_y0) * W + e_x0) * rec + (oct0 & 3) * 32;
+                    const unsigned voff = (unsigned)((4 * w4 * W + lje) * rec + lke * 16);
+                    const unsigned rowb = (unsigned)(W * rec);
+                    const bool chan_ok = col_ok && oct0 + (lke >> 1) < od.octs;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + ba + (n * 4 + lke) * 16);
+                    f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (ACT_C == ACT_ALPHA || (ACT_C < 0 && a.act == ACT_ALPHA)) av = *reinterpret_cast<const f32x4*>(smem + ba + NT * 64 + (n * 4 + lke) * 16);
+                    static_for<0, 4>([&](auto m_) DCSCN_INL {
+                        constexpr int m = decltype(m_)::value;
+                        f32x4 v = acc[m][n] * inv + bv;
+                        if constexpr (ACT_C == ACT_ALPHA) {
+                            v.x = v.x > 0.0f ? v.x : av.x * v.x;
+                            v.y = v.y > 0.0f ? v.y : av.y * v.y;
+                            v.z = v.z > 0.0f ? v.z : av.z * v.z;
+                            v.w = v.w > 0.0f ? v.w : av.w * v.w;
+                        } else if constexpr (ACT_C < 0) {
+                            chk = nonfinite_acc(chk, acc[m][n], zero);     // (a saturating activator hides a non-finite accumulator)
+                            v.x = activate1(v.x, av.x, a.act);
+                            v.y = activate1(v.y, av.y, a.act);
+                            v.z = activate1(v.z, av.z, a.act);
+                            v.w = activate1(v.w, av.w, a.act);
+                        }
+                        const u32x4 unit = p16_unit(v, m1, chk, zero2);
+                        if (chan_ok && (!MASK || e_y0 + 4 * w4 + m < H)) *reinterpret_cast<u32x4*>(base + (size_t)(voff + m * rowb)) = unit;
+                    });
+                });
+            };
+            if (e_full) {
+                if (a.act == ACT_ALPHA) finish(std::integral_constant<int, ACT_ALPHA>{}, std::false_type{});
+                else if (a.act == ACT_NONE) finish(std::integral_constant<int, ACT_NONE>{}, std::false_type{});
+                else finish(std::integral_constant<int, -1>{}, std::false_type{});
+            } else {
+                if (a.act == ACT_ALPHA) finish(std::integral_constant<int, ACT_ALPHA>{}, std::true_type{});
+                else finish(std::integral_constant<int, -1>{}, std::true_type{});
+            }
+            if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + e_img] = 1; }     // the image goes to the float32 plan (exec.hip)
+            pending = false;
+            if constexpr (DBG == 1) { pr_epi += __builtin_readcyclecounter() - pr_a; ++pr_items; }
+            return;
+        }
         if (fastable && e_full) {
             auto finish = [&](auto act_c) DCSCN_INL {
                 constexpr int ACT_C = decltype(act_c)::value;
@@ -398,8 +491,9 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
             const char* li_base = ends ? nxt.a_base : cur.a_base;
             const unsigned li_ok = ends ? nxt.ok_mask : cur.ok_mask;
             const bool li_all_in = ends ? nxt.all_in : cur.all_in;
+            const int li_pix0 = ends ? nxt.pix0 : cur.pix0;
             const int lchunk = ends ? 0 : chunk + 1;
-            const int img_off = ibuf * G::IN_BYTES;
+            const int img_off = ibuf * G::IN_BUF;
             static_for<0, 9>([&](auto s_) DCSCN_INL {
                 constexpr int step = decltype(s_)::value;
                 constexpr int kx = step / 3, ky = step % 3;
@@ -438,11 +532,17 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     dma_f(src, (step + 2) % 3 == 0 ? sl0 : (step + 2) % 3 == 1 ? sl1 : sl2, CNT);
                 };
                 if constexpr (!DMA_LATE) dma_ahead();
-                if constexpr (step == 0 && !(C3E_ABL & 2)) load_in(li_base, li_ok, lchunk);
-                if constexpr (step >= 3 && !(C3E_ABL & 2)) convert_store(std::integral_constant<int, step - 3>{}, li_all_in, li_ok, lchunk, ibuf ^ 1);
+                // P16: one image piece of the next chunk per step at steps 1 .. 6, BEHIND the filter pieces (buffer ibuf ^ 1 is read until the
+                // barrier that ends step 0: half 1's COMPUTE(8) of the previous chunk runs in that segment)
+                constexpr int IMG = P16 && step >= 1 && step <= L ? 1 : 0, IMG_PREV = P16 && step >= 2 && step <= L + 1 ? 1 : 0;
+                if constexpr (P16) { if constexpr (IMG) img_piece(std::integral_constant<int, step - 1>{}, li_pix0, li_ok, lchunk, ibuf ^ 1); }
+                else {
+                    if constexpr (step == 0 && !(C3E_ABL & 2)) load_in(li_base, li_ok, lchunk);
+                    if constexpr (step >= 3 && !(C3E_ABL & 2)) convert_store(std::integral_constant<int, step - 3>{}, li_all_in, li_ok, lchunk, ibuf ^ 1);
+                }
                 if constexpr (step == 0) { if (chunk == 0 && pending) epilogue(); }
-                // half 1, one barrier per tap: the next tap's pieces were issued behind the previous barrier; only this step's image loads are younger
-                if constexpr (DMA_LATE) { if constexpr (step == 0) c3p_wait_vm<L>(); else c3p_wait_vm<0>(); }
+                // half 1, one barrier per tap: the next tap's pieces were issued behind the previous barrier; only this step's image loads / piece are younger
+                if constexpr (DMA_LATE) { if constexpr (P16) c3p_wait_vm<IMG>(); else if constexpr (step == 0) c3p_wait_vm<L>(); else c3p_wait_vm<0>(); }
                 if constexpr (DBG == 1) pr_load += __builtin_readcyclecounter() - pr_a;
                 phase_barrier(bar_l, pr_bl);
                 // ================= COMPUTE phase =================
@@ -477,7 +577,8 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                 mfmas(std::integral_constant<int, CNT>{});
                 // half 0, one barrier per tap: the NEXT tap's pieces (issued in the previous load phase) must have landed before the barrier;
                 // younger than them: this load phase's F pieces, and the six image loads of a step 0 during the two steps after it
-                if constexpr (C3E_SB && HALF == 0) { if constexpr (step <= 1) c3p_wait_vm<F + L>(); else c3p_wait_vm<F>(); }
+                // P16: younger than LOAD(t - 1)'s filter pieces are its image piece (issued behind them), LOAD(t)'s F pieces and its image piece
+                if constexpr (C3E_SB && HALF == 0) { if constexpr (P16) c3p_wait_vm<F + IMG + IMG_PREV>(); else if constexpr (step <= 1) c3p_wait_vm<F + L>(); else c3p_wait_vm<F>(); }
                 if constexpr (DBG == 1) pr_comp += __builtin_readcyclecounter() - pr_a;
                 phase_barrier(bar_c, pr_bc);
                 ++tt;
@@ -486,19 +587,24 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         }
         // ---- packed tail: (tap, octet) pairs four to an instruction; the next item's first image is staged here ----
         if (octs) {
-            const int img_off = ibuf * G::IN_BYTES;
+            const int img_off = ibuf * G::IN_BUF;
             int l = lane;
             asm volatile("" : "+v"(l));
             auto tail_step = [&](int step, auto first_c) DCSCN_INL {
                 constexpr bool FIRST = decltype(first_c)::value;
                 if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
                 if constexpr (!C3E_SB) { if (!FIRST && step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>(); }
+                if constexpr (!P16)
                 if (!FIRST && step == 2 && !(C3E_ABL & 2)) {
                     if constexpr (C3E_SB && HALF == 0) c3p_wait_vm<F>();      // the image loads of tail step 0 (younger: step 1's pieces)
                     static_for<0, L>([&](auto r_) DCSCN_INL { convert_store(r_, nxt.all_in, nxt.ok_mask, 0, ibuf ^ 1); });
                 }
                 if constexpr (!DMA_LATE) dma_f(tap_src(cur, nxt, tt + 2), sl2, CNT);
-                if constexpr (FIRST && !(C3E_ABL & 2)) load_in(nxt.a_base, nxt.ok_mask, 0);
+                if constexpr (P16) {
+                    // the next item's first image: all L pieces at tail step 1 (buffer ibuf ^ 1 is read until the barrier that ends tail step 0),
+                    // behind the filter pieces; complete at the end of tail step 2 (n_tail >= 3)
+                    if constexpr (!FIRST) { if (step == 1) static_for<0, L>([&](auto r_) DCSCN_INL { img_piece(r_, nxt.pix0, nxt.ok_mask, 0, ibuf ^ 1); }); }
+                } else if constexpr (FIRST && !(C3E_ABL & 2)) load_in(nxt.a_base, nxt.ok_mask, 0);
                 const int pair = 4 * step + (l >> 4);
                 int tap = octs == 1 ? pair : octs == 2 ? pair >> 1 : (pair * 11) >> 5;
                 const int oct = pair - tap * octs;
@@ -517,7 +623,10 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     wb[p] = *reinterpret_cast<const h8*>(fs + (2 * p) * 1024);       // (tiles past the half's last: stale bytes of its own slot, never used)
                     wa[p] = *reinterpret_cast<const h8*>(fs + (2 * p + 1) * 1024);
                 });
-                if constexpr (DMA_LATE) { if constexpr (FIRST) c3p_wait_vm<L>(); else c3p_wait_vm<0>(); }
+                if constexpr (DMA_LATE) {
+                    if constexpr (P16) { if (!FIRST && step == 1) c3p_wait_vm<L>(); else c3p_wait_vm<0>(); }
+                    else if constexpr (FIRST) c3p_wait_vm<L>(); else c3p_wait_vm<0>();
+                }
                 if constexpr (DBG == 1) pr_load += __builtin_readcyclecounter() - pr_a;
                 phase_barrier(bar_l, pr_bl);
                 if constexpr (DBG == 1) pr_a = __builtin_readcyclecounter();
@@ -537,7 +646,10 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                     });
                 };
                 mfmas(std::integral_constant<int, CNT>{});
-                if constexpr (C3E_SB && HALF == 0) { if (FIRST || step == 1) c3p_wait_vm<F + L>(); else c3p_wait_vm<F>(); }
+                if constexpr (C3E_SB && HALF == 0) {
+                    if constexpr (P16) { if (!FIRST && step == 1) c3p_wait_vm<F + L>(); else c3p_wait_vm<F>(); }
+                    else if (FIRST || step == 1) c3p_wait_vm<F + L>(); else c3p_wait_vm<F>();
+                }
                 if constexpr (DBG == 1) pr_comp += __builtin_readcyclecounter() - pr_a;
                 phase_barrier(bar_c, pr_bc);
                 ++tt;

@@ -11,11 +11,30 @@ namespace dcscn {
 // prelu / relu / leaky_relu all become ACT_ALPHA with a per-channel negative slope.
 enum { ACT_NONE = 0, ACT_ALPHA = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_SELU = 4 };
 
+// Pre-split activation tensor ("P16", p16.hpp): what a split16 kernel consumes, stored once in the form it consumes it.  Per 32-channel
+// chunk one plane [zero record of 128 bytes][pixel records]; a record holds, per channel octet of the chunk, the 8 `hi` halfs and the
+// 8 `lo` halfs of split16.hpp as two 16-byte units: 128 bytes for a full chunk, 32 * octets for the last one.  Same 4 bytes per value
+// as float32, every record of a full chunk is one aligned 128-byte line.
+struct P16Desc {
+    char*     base;   // plane of chunk 0 (nullptr: the tensor is float32 NHWC)
+    long long plane;  // bytes between the planes of consecutive chunks
+    int32_t   octs;   // channel octets of the tensor = ceil(channels / 8); chunk c holds octets [4c, 4c + 4)
+    int32_t   pad_;
+};
+__host__ __device__ constexpr int p16_rec_bytes(int octs, int chunk) { return octs - 4 * chunk >= 4 ? 128 : 32 * (octs - 4 * chunk); }
+__host__ __device__ constexpr long long p16_plane_bytes(long long npix) { return ((npix + 1) * 128 + 255) & ~255LL; }
+__host__ __device__ constexpr long long p16_tensor_bytes(long long npix, int octs) {
+    return ((octs + 3) / 4 - 1) * p16_plane_bytes(npix) + ((128 + npix * p16_rec_bytes(octs, (octs + 3) / 4 - 1) + 255) & ~255LL);
+}
+// pixels per pass a P16 tensor can hold: record offsets are 32-bit (128 bytes * (pixel + 1))
+constexpr long long kP16MaxPixels = (1LL << 25) - 2;
+
 struct OutDesc {
     float*  ptr;      // base of the destination tensor (NHWC, possibly a wider concat buffer)
     int32_t stride;   // floats per pixel in the destination
     int32_t off;      // first channel of the slice written
     int32_t width;    // number of conv output channels stored through this descriptor
+    P16Desc p16;      // base != nullptr: the destination is a P16 tensor (off = first channel, a multiple of 16); ptr / stride unused
 };
 
 struct NinSrcQuad {           // conv_nin multi-source input: one 16-byte channel quad of the virtual concat
@@ -28,6 +47,7 @@ struct NinSrcQuad {           // conv_nin multi-source input: one 16-byte channe
 // helper/tf_graph.py:104-153; optional depth_to_space and residual add folded into the store).
 struct ConvArgs {
     const float* in;          // NHWC source, [n, H, W, in_stride]
+    P16Desc in16;             // base != nullptr: the source is a P16 tensor read from channel 0 (split16 kernels only); in / in_stride unused
     int32_t in_stride;
     int32_t in_off;           // first channel of the slice read (multiple of 4)
     int32_t cin_phys;         // physical channels read (multiple of 4)
