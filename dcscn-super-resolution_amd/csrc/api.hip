@@ -169,6 +169,16 @@ int dcscn_finalize(dcscn_handle h) {
     for (Op& op : h->ops) {
         int rc = finalize_op(h, op);
         if (rc) return rc;
+    }
+    plan_p16(h);
+    for (Op& op : h->ops) {
+        int rc = DCSCN_OK;
+        if (op.kind == OP_CONV && op.shape.nin && op.h16.on && op.h16.in16_ok) {
+            // conv_nin_h with P16 sources: 4 octet entries per 32-channel chunk
+            op.h16.h_tab16.assign((size_t)4 * op.h16.n_chunks, NinSrcQuad{0, 0, 0});
+            rc = upload(h, op.h16.h_tab16.data(), op.h16.h_tab16.size() * sizeof(NinSrcQuad), (void**)&op.h16.d_tab16);
+            if (rc) return rc;
+        }
         if (!op.multi.empty()) {
             // 4 quads per 16-channel chunk of conv_nin; conv_nin_h walks the same table 8 quads per 32-channel chunk
             op.h_srctab.assign(std::max<size_t>((size_t)4 * op.n_chunks, (size_t)8 * ((op.cin_phys + kNinHKC - 1) / kNinHKC)), NinSrcQuad{0, 0, 0});
@@ -198,10 +208,8 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     const Op& op = h->ops[index];
     memset(out, 0, sizeof *out);
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
-    const bool s16 = h->split16 && op.h16.on && (h->split16_mask & (op.shape.nin ? 2 : 1));
-    // conv3_h8 takes what c3e_eligible (conv3_h8.hip) accepts: two channel groups of 4..6 tiles, no depth_to_space, no residual
-    const bool h8 = s16 && h->conv3_h8 && !op.shape.nin && op.fold_s == 0 && op.h16.n_tiles == 2 && op.h16.nt >= 4 && op.h16.nt <= 6 && op.ps == 1 && !op.residual &&
-                    (op.act == ACT_ALPHA || op.act == ACT_NONE) && op.h16.n_chunks >= 3;
+    const bool s16 = op_on_split16(h, op);
+    const bool h8 = op_takes_h8(h, op);                          // (the predicate launch_op itself uses)
     snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (s16 ? (op.shape.nin ? "conv_nin_h" : op.fold_s > 0 ? "conv5_h" : h8 ? "conv3_h8" : "conv3_h") : op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
@@ -289,6 +297,10 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "split16")) {                  // any time: the f16 images are always built, the option picks the launch
         h->split16 = value != 0;
         h->split16_mask = value == 2 ? 1 : value == 3 ? 2 : 3;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "p16")) {                      // any time: the next forward re-carves the workspace (1 = pre-split tensors between split16 launches)
+        h->p16 = value != 0;
         return DCSCN_OK;
     }
     if (!strcmp(key, "conv3_h8")) {                 // any time: the two kernels take the same filter image
@@ -648,22 +660,23 @@ int dcscn_get_profile(dcscn_handle h, double* ms, int capacity) {
     if (!h) return DCSCN_ERR_INVALID_ARG;
     if (!ms || capacity < 0) return fail(h, DCSCN_ERR_INVALID_ARG, "dcscn_get_profile: bad argument");
     const int nops = (int)h->ops.size();
-    std::vector<double> acc(nops, 0.0);
+    std::vector<double> acc(nops + 1, 0.0);                 // [nops]: the float32 plan behind the passes (gated launches that normally exit at once)
     const int forwards = h->ev_forwards;
     if (h->ev_used > 0) {
         HIP_TRY(h, hipDeviceSynchronize());
         const size_t launches = h->ev_used / 2;
-        for (size_t l = 0; l < launches; ++l) {
+        for (size_t l = 0; l < launches && l < h->ev_op.size(); ++l) {
             float t = 0.0f;
             HIP_TRY(h, hipEventElapsedTime(&t, h->ev[2 * l], h->ev[2 * l + 1]));
-            acc[l % nops] += t;
+            acc[std::min(std::max(h->ev_op[l], 0), nops)] += t;
         }
     }
     h->ev_used = 0;
     h->ev_forwards = 0;
+    h->ev_op.clear();
     if (forwards > 1)
         for (double& v : acc) v /= forwards;
-    for (int i = 0; i < std::min(capacity, nops); ++i) ms[i] = acc[i];
+    for (int i = 0; i < std::min(capacity, nops + 1); ++i) ms[i] = acc[i];
     return DCSCN_OK;
 }
 
@@ -678,6 +691,14 @@ int dcscn_debug_digests(dcscn_handle h, uint64_t* out, int capacity) {
 }
 
 int64_t dcscn_workspace_bytes(dcscn_handle h) { return h ? (int64_t)h->arena_bytes : -1; }
+
+int dcscn_num_p16_tensors(dcscn_handle h) {
+    if (!h) return -DCSCN_ERR_INVALID_ARG;
+    if (!h->finalized || !p16_active(h)) return 0;
+    int n = 0;
+    for (const WsBuf& b : h->bufs) n += b.p16_ok && b.stride > 0;
+    return n;
+}
 
 const char* dcscn_last_error(dcscn_handle h) { return h ? h->error.c_str() : g_global_error.c_str(); }
 
@@ -707,6 +728,8 @@ int dcscn_destroy(dcscn_handle h) {
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (void* p : h->device_allocs) (void)hipFree(p);
     if (h->arena) (void)hipFree(h->arena);
+    if (h->d_zrec) (void)hipFree(h->d_zrec);
+    if (h->d_digest) (void)hipFree(h->d_digest);
     for (float* p : {h->tile_x, h->tile_x2, h->tile_y, h->rs_tmp, h->rs_in, h->rs_out, h->ens_x, h->ens_x2, h->ens_y, h->ens_out, h->col_rgb, h->col_d,
                      h->col_d2, h->col_y32})
         if (p) (void)hipFree(p);

@@ -8,8 +8,13 @@ static hipError_t c3h_set_attr() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_h<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, C3HGeom<NT>::LDS_BYTES);
 }
 
+hipError_t c3h16_init_kernels();                                // conv3_h_p16.hip: the variants that read a P16 tensor
+hipError_t c3h16_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream);
+
 hipError_t c3h_init_kernels() {
-    hipError_t e = c3h_set_attr<1>();
+    hipError_t e = c3h16_init_kernels();
+    if (e != hipSuccess) return e;
+    e = c3h_set_attr<1>();
     if (e == hipSuccess) e = c3h_set_attr<2>();
     if (e == hipSuccess) e = c3h_set_attr<3>();
     if (e == hipSuccess) e = c3h_set_attr<4>();
@@ -34,6 +39,7 @@ hipError_t c3h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t strea
     if (a.n_full < 1 || a.n_full > n_groups || (nt == 1 && a.n_full != n_groups) || !a.wpack16 || a.tiles_x != (a.W + 15) / 16 ||
         a.tiles_y != (a.H + 15) / 16 || a.n_chunks < 1)
         return hipErrorInvalidValue;
+    if (a.in16.base) return c3h16_launch(nt, a, n_groups, stream);
     switch (nt) {
         case 1: return c3h_launch_one<1>(a, n_groups, stream);
         case 2: return c3h_launch_one<2>(a, n_groups, stream);

@@ -36,6 +36,7 @@
 #pragma once
 #include "conv_wino2.hpp"
 #include "split16.hpp"
+#include "p16.hpp"
 #ifndef C3H_EXP
 #define C3H_EXP 0
 #endif
@@ -110,7 +111,11 @@ static_assert(c3h_writes_conflict_free(), "c3h_unit: the two columns of an image
 // 6 = 2 + 3 + 4 (LDS reads and MFMAs only); 7 / 8 = shipped + shader-clock probes (per wave, through a.srctab: [0] entry, [1] K loop
 // start, [2] K loop end, [3] exit, [4] sum over taps of (wait + barrier) [7] or of the DMA / load issue behind it [8], [5] sum of the
 // chunk-boundary barrier + image write, [6] HW_ID)
-template <int NT, int NTV, int ABL = 0>
+// IN16: the input is a P16 tensor (a.in16, p16.hpp): the staged item is one 16-byte (hi | lo) unit -- fetched with the c3h_unit
+// permutation on the source side, written to LDS as it is (ds_write_b128 at the lane-linear position), out-of-image pixels and octets past
+// the tensor's last read the plane's zero record: no conversion, no select, half the LDS store instructions.
+// Destinations may be P16 tensors (OutDesc::p16), each on its own: the epilogue then stores (hi | lo) units.
+template <int NT, int NTV, int ABL = 0, bool IN16 = false>
 __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int tile_id, int ntile) {
     using G = C3HGeom<NT>;
     const int tid = threadIdx.x;
@@ -130,9 +135,9 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
     const int y0 = ty * G::TH;
     const int x0 = tx * G::TW;
     const int H = a.H, W = a.W;
-    const float* in_img = a.in + (size_t)img * H * W * a.in_stride + a.in_off;
     // origin of the halo tile; only in-image addresses are ever dereferenced (out-of-image items read the tile's own first pixel)
-    const float* a_base = in_img + ((ptrdiff_t)(y0 - 1) * W + (x0 - 1)) * a.in_stride;
+    const float* a_base = IN16 ? nullptr : a.in + (size_t)img * H * W * a.in_stride + a.in_off + ((ptrdiff_t)(y0 - 1) * W + (x0 - 1)) * a.in_stride;
+    const int pix0 = (img * H + y0 - 1) * W + x0 - 1;         // IN16: flat pixel index of the halo tile's origin (may be negative)
 
     // ---- staging plan of the input image: item = r * 256 + tid = (halo pixel, channel quad) ----
     const int cq = tid & 7;                                   // channel quad of every item of this thread
@@ -163,6 +168,25 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
 
     f32x4 gin[G::IN_ROUNDS];
     auto load_in = [&](int chunk) DCSCN_INL {
+        if constexpr (IN16) {
+            const int rem = a.in16.octs - 4 * chunk;           // octets of this chunk (block uniform)
+            const int rec = rem >= 4 ? 128 : 32 * rem;
+            const char* base = a.in16.base + (long long)chunk * a.in16.plane;
+            int hp0 = tid >> 3;
+            asm volatile("" : "+v"(hp0));
+            int hrow = hp0 >= G::HT ? 1 : 0, hcol = hp0 - G::HT * hrow;
+            static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
+                constexpr int r = decltype(r_)::value;
+                const int kq = ((cq >> 1) - (hcol >> 1)) & 3;  // the unit c3h_unit puts at slot cq of this halo column
+                const int part = (cq ^ kq ^ hcol) & 1;
+                const bool ok = ((ok_mask >> r) & 1u) && kq < rem;
+                const unsigned off = ok ? (unsigned)(128 + (pix0 + hrow * W + hcol) * rec + (2 * kq + part) * 16) : (unsigned)(cq * 16);
+                gin[r] = *reinterpret_cast<const f32x4*>(base + (size_t)off);
+                hcol += 32 - G::HT; hrow += 1;
+                if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
+            });
+            return;
+        }
         const int c0 = chunk * G::KC + cq * 4;
         const unsigned coff = (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4);   // channels past cin: read something valid, written as zeros
         // wave-uniform 64-bit base + 32-bit lane offset: the loads take the SGPR-base form, no 64-bit pointer per item is kept live
@@ -183,6 +207,7 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
     // item r of the chunk in flight: f32 values -> (hi, lo) pairs, in place (gin[r] = {hi01, hi23, lo01, lo23})
     auto convert_in = [&](auto r_, int chunk) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
+        if constexpr (IN16) return;
         f32x4 x = gin[r];
         const bool whole = all_in && (chunk + 1) * G::KC <= a.cin_phys;       // block uniform: nothing to zero
         if (!whole) {
@@ -204,6 +229,9 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
             const int kq = cq >> 1;
             const int off = hp * G::PIX_BYTES + c3h_unit(hcol, kq, 0) * 16 + (cq & 1) * 8;
             const u32x4 v = __builtin_bit_cast(u32x4, gin[r]);
+            if constexpr (IN16) {
+                if (r < G::IN_ROUNDS - 1 || hp < G::HP) *reinterpret_cast<u32x4*>(smem + hp * G::PIX_BYTES + cq * 16) = v;
+            } else
             if (r < G::IN_ROUNDS - 1 || hp < G::HP) {
                 *reinterpret_cast<u32x2*>(smem + off) = u32x2{v.x, v.y};
                 *reinterpret_cast<u32x2*>(smem + (off ^ 16)) = u32x2{v.z, v.w};
@@ -472,13 +500,87 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
             });
         });
     };
-    const bool fast = ps == 1 && a.res == nullptr && (a.split & 15) == 0 && y0 + G::TH <= H && x0 + G::TW <= W;   // block uniform
+    // P16 destination(s) (plain NHWC geometry: no depth_to_space, no residual): one (hi | lo) unit per lane and tile, one 64-bit base per
+    // tile and 32-bit lane offsets; a float32 destination beside a P16 one takes the plain store
+    auto finish16 = [&](auto act_c, auto mask_c) DCSCN_INL {
+        constexpr int ACT_C = decltype(act_c)::value;
+        constexpr bool MASK = decltype(mask_c)::value;
+        const h2 zero2 = p16_opaque_zero2();
+        const int cb16 = ntile * NT * 16 - 16 * (ntile > a.n_full ? ntile - a.n_full : 0);
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int lje = le & 15, lke = le >> 4;
+        const bool col_ok = !MASK || x0 + lje < W;
+        static_for<0, NTV>([&](auto n_) DCSCN_INL {
+            constexpr int n = decltype(n_)::value;
+            const int c0 = cb16 + n * 16;
+            const bool first = c0 < a.split;
+            const OutDesc& od = first ? a.out0 : a.out1;
+            const int cc0 = first ? c0 : c0 - a.split;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + G::BA_BASE + (n * 4 + lke) * 16);
+            f32x4 av = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (ACT_C == ACT_ALPHA || (ACT_C < 0 && act == ACT_ALPHA)) av = *reinterpret_cast<const f32x4*>(smem + G::BA_BASE + NT * 64 + (n * 4 + lke) * 16);
+            char* base;
+            unsigned voff, rowb;
+            bool chan_ok;
+            const bool o16 = od.p16.base != nullptr;              // block uniform
+            if (o16) {
+                const int oct0 = (od.off + cc0) >> 3;
+                const int chunk = oct0 >> 2, rem = od.p16.octs - 4 * chunk;
+                const int rec = rem >= 4 ? 128 : 32 * rem;
+                base = od.p16.base + (long long)chunk * od.p16.plane + 128 + (long long)((img * H + y0) * W + x0) * rec + (oct0 & 3) * 32;
+                voff = (unsigned)((4 * wave * W + lje) * rec + lke * 16);
+                rowb = (unsigned)(W * rec);
+                chan_ok = col_ok && oct0 + (lke >> 1) < od.p16.octs;
+            } else {
+                base = reinterpret_cast<char*>(od.ptr + ((size_t)(img * H + y0) * W + x0) * od.stride + od.off + cc0);
+                voff = (unsigned)(((4 * wave * W + lje) * od.stride + 4 * lke) * 4);
+                rowb = (unsigned)(W * od.stride * 4);
+                chan_ok = col_ok && cc0 + 4 * lke < od.width;
+            }
+            static_for<0, 4>([&](auto m_) DCSCN_INL {
+                constexpr int m = decltype(m_)::value;
+                f32x4 v = acc[m][n] * inv + bv;
+                if constexpr (ACT_C == ACT_ALPHA) {
+                    v.x = v.x > 0.0f ? v.x : av.x * v.x;
+                    v.y = v.y > 0.0f ? v.y : av.y * v.y;
+                    v.z = v.z > 0.0f ? v.z : av.z * v.z;
+                    v.w = v.w > 0.0f ? v.w : av.w * v.w;
+                } else if constexpr (ACT_C < 0) {
+                    v.x = activate1(v.x, av.x, act);
+                    v.y = activate1(v.y, av.y, act);
+                    v.z = activate1(v.z, av.z, act);
+                    v.w = activate1(v.w, av.w, act);
+                }
+                const bool row_ok = !MASK || y0 + 4 * wave + m < H;
+                if (o16) {
+                    if constexpr (ACT_C < 0) chk = nonfinite_acc(chk, acc[m][n], zero);   // (a saturating activator hides a non-finite accumulator)
+                    const u32x4 unit = p16_unit(v, m1, chk, zero2);
+                    if (chan_ok && row_ok) *reinterpret_cast<u32x4*>(base + (size_t)(voff + m * rowb)) = unit;
+                } else {
+                    chk = nonfinite_acc(chk, acc[m][n], zero);
+                    if (chan_ok && row_ok) *reinterpret_cast<f32x4*>(base + (size_t)(voff + m * rowb)) = v;
+                }
+            });
+        });
+    };
+    const bool any16 = a.out0.p16.base != nullptr || a.out1.p16.base != nullptr;                                    // block uniform
+    const bool whole_tile = y0 + G::TH <= H && x0 + G::TW <= W;
+    if (any16) {
+        if (whole_tile && act == ACT_ALPHA) finish16(std::integral_constant<int, ACT_ALPHA>{}, std::false_type{});
+        else if (whole_tile && act == ACT_NONE) finish16(std::integral_constant<int, ACT_NONE>{}, std::false_type{});
+        else if (act == ACT_ALPHA) finish16(std::integral_constant<int, ACT_ALPHA>{}, std::true_type{});
+        else finish16(std::integral_constant<int, -1>{}, std::true_type{});
+        if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + img] = 1; }
+        return;
+    }
+    const bool fast = ps == 1 && a.res == nullptr && (a.split & 15) == 0 && whole_tile;   // block uniform
     if (fast && act == ACT_ALPHA) finish_fast(std::integral_constant<int, ACT_ALPHA>{});
     else if (fast && act == ACT_NONE) finish_fast(std::integral_constant<int, ACT_NONE>{});
     else if (act == ACT_ALPHA) finish(std::integral_constant<int, ACT_ALPHA>{});
     else if (act == ACT_NONE) finish(std::integral_constant<int, ACT_NONE>{});
     else finish(std::integral_constant<int, -1>{});
-    if (chk != chk && a.redo) a.redo[tile_id] = 1;
+    if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + img] = 1; }     // the image goes to the float32 plan (exec.hip)
     if constexpr (PROBE) {
         if (lane == 0 && a.srctab) {
             long long* pr = reinterpret_cast<long long*>(const_cast<void*>(a.srctab)) + ((size_t)blockIdx.x * 4 + wave) * 8;
@@ -494,7 +596,7 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
 
 // 1-D grid decoded as conv_wino2's: the channel groups of one pixel tile get ids that are congruent mod 8 and close together
 // (same XCD, about the same time: the input tile is shared through that XCD's L2)
-template <int NT, int WPS = 2, int ABL = 0>
+template <int NT, int WPS = 2, int ABL = 0, bool IN16 = false>
 __global__ __launch_bounds__(256, WPS) void conv3_h(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_c3h[];
     const int Gn = a.n_groups, S = a.group_span;
@@ -509,8 +611,8 @@ __global__ __launch_bounds__(256, WPS) void conv3_h(const ConvArgs a) {
     const int ntile = phase * S + (r >> 3);
     const int tile_id = q * 8 + (r & 7);
     if (tile_id >= a.N * a.tiles_y * a.tiles_x) return;
-    if (ntile < a.n_full) conv3_h_body<NT, NT, ABL>(a, smem_c3h, tile_id, ntile);                 // block uniform
-    else if constexpr (NT >= 2) conv3_h_body<NT, NT - 1, ABL>(a, smem_c3h, tile_id, ntile);
+    if (ntile < a.n_full) conv3_h_body<NT, NT, ABL, IN16>(a, smem_c3h, tile_id, ntile);                 // block uniform
+    else if constexpr (NT >= 2) conv3_h_body<NT, NT - 1, ABL, IN16>(a, smem_c3h, tile_id, ntile);
 }
 
 }  // namespace dcscn

@@ -8,8 +8,13 @@ static hipError_t c3e_set_attr() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_h8<NT, C1>), hipFuncAttributeMaxDynamicSharedMemorySize, C3EGeom<NT>::LDS_BYTES);
 }
 
+hipError_t c3e16_init_kernels();                                // conv3_h8_p16.hip: P16 tensors in and out
+hipError_t c3e16_launch(int nt, const ConvArgs& a, int wgs, hipStream_t stream);
+
 hipError_t c3e_init_kernels() {
-    hipError_t e = c3e_set_attr<6, 6>();
+    hipError_t e = c3e16_init_kernels();
+    if (e != hipSuccess) return e;
+    e = c3e_set_attr<6, 6>();
     if (e == hipSuccess) e = c3e_set_attr<6, 5>();
     if (e == hipSuccess) e = c3e_set_attr<5, 5>();
     if (e == hipSuccess) e = c3e_set_attr<5, 4>();
@@ -38,6 +43,10 @@ hipError_t c3e_launch(int nt, const ConvArgs& args, int n_groups, int n_cus, hip
     const long long units = (long long)a.N * a.tiles_y * a.tiles_x;     // one (pixel tile, group pair) per unit
     if (units > 0x7fffffffLL) return hipErrorInvalidValue;
     const int wgs = (int)(units < n_cus ? units : n_cus);                 // one persistent workgroup per CU
+    // P16 in and out (p16.hpp): the variant that stages its image by LDS-DMA; float32 in and out: the r04 kernel; anything mixed is not ours
+    const bool out16 = a.out0.p16.base != nullptr && (a.split >= (1 << 29) || a.out1.p16.base != nullptr);
+    if (a.in16.base && out16) return c3e16_launch(nt, a, wgs, stream);
+    if (a.in16.base || a.out0.p16.base || a.out1.p16.base) return hipErrorInvalidValue;
     const bool eq = a.n_full == 2;
     switch (nt) {
         case 6: return eq ? c3e_launch_one<6, 6>(a, wgs, stream) : c3e_launch_one<6, 5>(a, wgs, stream);

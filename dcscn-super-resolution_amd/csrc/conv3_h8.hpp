@@ -454,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                 });
             });
         }
-        if (chk != chk && a.redo) a.redo[e_tile] = 1;
+        if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + e_img] = 1; }     // the image goes to the float32 plan (exec.hip)
         pending = false;
         if constexpr (DBG == 1) { pr_epi += __builtin_readcyclecounter() - pr_a; ++pr_items; }
     };

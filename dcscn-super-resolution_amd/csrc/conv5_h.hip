@@ -5,7 +5,9 @@ namespace dcscn {
 
 template <int NT>
 static hipError_t c5h_set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_h<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, C5HGeom<NT>::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_h<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C5HGeom<NT>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_h<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C5HGeom<NT>::LDS_BYTES);
 }
 
 hipError_t c5h_init_kernels() {
@@ -18,7 +20,11 @@ template <int NT>
 static hipError_t c5h_launch_one(const ConvArgs& a, hipStream_t stream) {
     const long long tiles = (long long)a.N * a.tiles_y * a.tiles_x;
     if (tiles > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv5_h<NT>), dim3((unsigned)tiles), dim3(256), C5HGeom<NT>::LDS_BYTES, stream, a);
+    if (a.in16.base) {
+        if ((long long)a.N * a.H * a.W > kP16MaxPixels) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((conv5_h<NT, true>), dim3((unsigned)tiles), dim3(256), C5HGeom<NT>::LDS_BYTES, stream, a);
+    } else
+        hipLaunchKernelGGL((conv5_h<NT, false>), dim3((unsigned)tiles), dim3(256), C5HGeom<NT>::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 

@@ -37,7 +37,8 @@ struct C5HGeom {
     static constexpr int LDS_BYTES = BA_BASE + NT * 64;
 };
 
-template <int NT>
+// IN16: the input is a P16 tensor (a.in16, p16.hpp), staged as in conv3_h<.., IN16>: one ready (hi | lo) unit per item, no conversion
+template <int NT, bool IN16 = false>
 __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a) {
     using G = C5HGeom<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem_c5h[];
@@ -57,9 +58,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
     const int y0 = ty * G::TH;
     const int x0 = tx * G::TW;
     const int H = a.H, W = a.W;
-    const float* in_img = a.in + (size_t)img * H * W * a.in_stride + a.in_off;
     // origin of the halo tile; only in-image addresses are dereferenced (out-of-image items read the tile's own first pixel)
-    const float* a_base = in_img + ((ptrdiff_t)(y0 - 2) * W + (x0 - 2)) * a.in_stride;
+    const float* a_base = IN16 ? nullptr : a.in + (size_t)img * H * W * a.in_stride + a.in_off + ((ptrdiff_t)(y0 - 2) * W + (x0 - 2)) * a.in_stride;
+    const int pix0 = (img * H + y0 - 2) * W + x0 - 2;         // IN16: flat pixel index of the halo tile's origin (may be negative)
 
     // ---- staging of the input image: item = r * 256 + tid = (halo pixel hp = r * 32 + (tid >> 3), channel quad tid & 7) ----
     const int cq = tid & 7;
@@ -84,6 +85,25 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
 
     f32x4 gin[G::IN_ROUNDS];
     auto load_in = [&](int chunk) DCSCN_INL {
+        if constexpr (IN16) {
+            const int rem = a.in16.octs - 4 * chunk;           // octets of this chunk (block uniform)
+            const int rec = rem >= 4 ? 128 : 32 * rem;
+            const char* base = a.in16.base + (long long)chunk * a.in16.plane;
+            int hp0 = tid >> 3;
+            asm volatile("" : "+v"(hp0));
+            int hrow = hp0 >= G::HT ? 1 : 0, hcol = hp0 - G::HT * hrow;
+            static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL {
+                constexpr int r = decltype(r_)::value;
+                const int kq = ((cq >> 1) - (hcol >> 1)) & 3;  // the unit c3h_unit puts at slot cq of this halo column
+                const int part = (cq ^ kq ^ hcol) & 1;
+                const bool ok = ((ok_mask >> r) & 1u) && kq < rem;
+                const unsigned off = ok ? (unsigned)(128 + (pix0 + hrow * W + hcol) * rec + (2 * kq + part) * 16) : (unsigned)(cq * 16);
+                gin[r] = *reinterpret_cast<const f32x4*>(base + (size_t)off);
+                hcol += 32 - G::HT; hrow += 1;
+                if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
+            });
+            return;
+        }
         const int c0 = chunk * G::KC + cq * 4;
         const unsigned coff = (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4);
         const char* base = reinterpret_cast<const char*>(a_base);
@@ -102,6 +122,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
     const float m1 = opaque_minus_one();
     auto convert_in = [&](auto r_, int chunk) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
+        if constexpr (IN16) return;
         f32x4 x = gin[r];
         const bool whole = all_in && (chunk + 1) * G::KC <= a.cin_phys;
         if (!whole) {
@@ -123,6 +144,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
             const int kq = cq >> 1;
             const int off = hp * G::PIX_BYTES + c3h_unit(hcol, kq, 0) * 16 + (cq & 1) * 8;
             const u32x4 v = __builtin_bit_cast(u32x4, gin[r]);
+            if constexpr (IN16) {
+                if (r < G::IN_ROUNDS - 1 || hp < G::HP) *reinterpret_cast<u32x4*>(smem + hp * G::PIX_BYTES + cq * 16) = v;
+            } else
             if (r < G::IN_ROUNDS - 1 || hp < G::HP) {
                 *reinterpret_cast<u32x2*>(smem + off) = u32x2{v.x, v.y};
                 *reinterpret_cast<u32x2*>(smem + (off ^ 16)) = u32x2{v.z, v.w};
@@ -235,7 +259,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
             });
         }
     });
-    if (chk != chk && a.redo) a.redo[tile_id] = 1;
+    if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + img] = 1; }     // the image goes to the float32 plan (exec.hip)
 }
 
 }  // namespace dcscn

@@ -114,13 +114,11 @@ __global__ __launch_bounds__(256, WPS) void conv_igemm(const ConvArgs a) {
     const int lk = lane >> 4;   // k index within the 4-deep MFMA step / channel quad of the result
 
     int bid = blockIdx.x;
-    if constexpr (G::TH == 16 && G::TW == 16) {
-        if (a.redo_check && a.redo[bid] == 0) return;          // fallback behind conv5_h: only the flagged 16x16 pixel tiles
-    }
     const int tx = bid % a.tiles_x;
     bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
     const int img = bid / a.tiles_y;
+    if (a.redo_check && (a.redo[0] == 0 || a.redo[1 + img] == 0)) return;   // float32 plan behind a split16 pass: flagged images only
     const int ntile = blockIdx.y;
     const int y0 = ty * G::TH;
     const int x0 = tx * G::TW;

@@ -232,7 +232,14 @@ __global__ __launch_bounds__(256, WPS) void conv_nin(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const long long pix0 = (long long)blockIdx.x * NinGeom<NT>::PIX;
     const int ntile = blockIdx.y;
-    if (a.redo_check && a.redo[blockIdx.x] == 0) return;       // fallback behind conv_nin_h: only the flagged pixel blocks
+    if (a.redo_check) {                                        // float32 plan behind a split16 pass: blocks that touch a flagged image
+        if (a.redo[0] == 0) return;
+        const long long hw = (long long)a.H * a.W, npix = hw * a.N;
+        const long long last = pix0 + NinGeom<NT>::PIX - 1 < npix ? pix0 + NinGeom<NT>::PIX - 1 : npix - 1;
+        bool any = false;
+        for (int i = (int)(pix0 / hw); i <= (int)(last / hw); ++i) any = any || a.redo[1 + i] != 0;
+        if (!any) return;
+    }
     if (ntile < a.n_full) conv_nin_body<NT, NT, MULTI>(a, smem, pix0, ntile);          // block uniform
     else if constexpr (NT >= 2) conv_nin_body<NT, NT - 1, MULTI>(a, smem, pix0, ntile);
 }

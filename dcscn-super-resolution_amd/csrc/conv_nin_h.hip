@@ -8,10 +8,13 @@ constexpr int kNinHMaxTable = 16 * 1024;         // LDS bytes for the multi-sour
 
 template <int NT>
 static hipError_t nin_h_set_attr() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin_h<NT, false, kNinHStages>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin_h<NT, 0, kNinHStages>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        NinHGeom<NT, kNinHStages>::LDS_BYTES);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin_h<NT, true, kNinHStages>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin_h<NT, 2, kNinHStages>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            NinHGeom<NT, kNinHStages>::LDS_BYTES + kNinHMaxTable);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_nin_h<NT, 1, kNinHStages>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                NinHGeom<NT, kNinHStages>::LDS_BYTES + kNinHMaxTable);
 }
 
@@ -29,12 +32,16 @@ static hipError_t nin_h_launch_one(const ConvArgs& a, int n_groups, hipStream_t 
     using G = NinHGeom<NT, kNinHStages>;
     const long long npix = (long long)a.N * a.H * a.W;
     const dim3 grid((unsigned)((npix + G::PIX - 1) / G::PIX), (unsigned)n_groups);
-    if (a.srctab) {
+    if (a.in16.base) {                                           // P16 sources: a.srctab holds one entry per channel OCTET (4 per chunk)
+        const size_t table = (size_t)a.n_chunks * 64;
+        if (!a.srctab || table > (size_t)kNinHMaxTable || npix > kP16MaxPixels) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((conv_nin_h<NT, 2, kNinHStages>), grid, dim3(256), G::LDS_BYTES + table, stream, a);
+    } else if (a.srctab) {
         const size_t table = (size_t)a.n_chunks * 128;           // 8 quads of 16 bytes per 32-channel chunk
         if (table > (size_t)kNinHMaxTable) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((conv_nin_h<NT, true, kNinHStages>), grid, dim3(256), G::LDS_BYTES + table, stream, a);
+        hipLaunchKernelGGL((conv_nin_h<NT, 1, kNinHStages>), grid, dim3(256), G::LDS_BYTES + table, stream, a);
     } else {
-        hipLaunchKernelGGL((conv_nin_h<NT, false, kNinHStages>), grid, dim3(256), G::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((conv_nin_h<NT, 0, kNinHStages>), grid, dim3(256), G::LDS_BYTES, stream, a);
     }
     return hipGetLastError();
 }

@@ -15,6 +15,7 @@
 #pragma once
 #include "conv_nin.hpp"
 #include "split16.hpp"
+#include "p16.hpp"
 
 namespace dcscn {
 
@@ -39,9 +40,13 @@ struct NinHGeom {
     static_assert(S == 2 || S == 3, "2 or 3 input stages");
 };
 
-template <int NT, int NTV, bool MULTI, int S>
+// SRC: 0 = one float32 tensor, 1 = MULTI (float32 sources through a per-quad table), 2 = P16 sources (p16.hpp) through a per-OCTET table:
+// entry = {address of the octet's hi unit in the record of pixel 0, record bytes}; the staged slot is then a ready (hi | lo) unit -- the B
+// fragments are read as they are, no split in registers.  Entries past the last octet point at a plane's zero record with stride 0.
+template <int NT, int NTV, int SRC, int S>
 __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, long long pix0, int ntile) {
     using G = NinHGeom<NT, S>;
+    constexpr bool MULTI = SRC != 0, IN16 = SRC == 2;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -78,12 +83,13 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
     typedef const volatile __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
     u32x4 ent = {0u, 0u, 0u, 0u};
     auto load_ent = [&](int chunk) DCSCN_INL {
-        if constexpr (MULTI) ent = *(lds_u32x4_ptr)(uintptr_t)(lds0 + G::LDS_BYTES + (unsigned)(chunk * 8 + dq) * 16u);
+        if constexpr (IN16) ent = *(lds_u32x4_ptr)(uintptr_t)(lds0 + G::LDS_BYTES + (unsigned)(chunk * 4 + d_kq) * 16u);
+        else if constexpr (MULTI) ent = *(lds_u32x4_ptr)(uintptr_t)(lds0 + G::LDS_BYTES + (unsigned)(chunk * 8 + dq) * 16u);
     };
     auto dma_a = [&](auto r_, int chunk, unsigned stage) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
         if constexpr (MULTI) {
-            const char* src = reinterpret_cast<const char*>(((unsigned long long)ent.y << 32) | ent.x) + (unsigned long long)a_pix[r] * ent.z;
+            const char* src = reinterpret_cast<const char*>(((unsigned long long)ent.y << 32) | ent.x) + (unsigned long long)a_pix[r] * ent.z + (IN16 ? (dq & 1) * 16 : 0);
             glds16v(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
         } else {
             const int c0 = chunk * G::KC + 4 * dq;
@@ -93,7 +99,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
 
     {
         if constexpr (MULTI)
-            for (int i = tid; i < 8 * a.n_chunks; i += G::THREADS)
+            for (int i = tid; i < (IN16 ? 4 : 8) * a.n_chunks; i += G::THREADS)
                 *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + G::LDS_BYTES + 16 * i) = reinterpret_cast<const f32x4*>(a.srctab)[i];
         __syncthreads();
     }
@@ -146,7 +152,8 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
         static_for<0, G::MT>([&](auto m_) DCSCN_INL {
             constexpr int m = decltype(m_)::value;
             h8 xh, xl;
-            split8(xa[m], xb[m], m1, xh, xl);
+            if constexpr (IN16) { xh = __builtin_bit_cast(h8, xa[m]); xl = __builtin_bit_cast(h8, xb[m]); }
+            else split8(xa[m], xb[m], m1, xh, xl);
             static_for<0, NTV>([&](auto n_) DCSCN_INL {
                 constexpr int n = decltype(n_)::value;
                 const h8 wh = *(lds_h8_ptr)(uintptr_t)(Bs + (2 * n) * 1024);
@@ -178,8 +185,10 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
     const int obase = cbase - 16 * (ntile > a.n_full ? ntile - a.n_full : 0);
     const int act = a.act;
     const float inv = a.inv_scale;
-    float chk = 0.0f;
+    float chk[G::MT];                                          // per pixel tile: the two pixels of a lane may belong to different images
+    static_for<0, G::MT>([&](auto m_) DCSCN_INL { chk[decltype(m_)::value] = 0.0f; });
     const float zero = opaque_zero();
+    const h2 zero2 = p16_opaque_zero2();
     auto finish = [&](auto act_c) DCSCN_INL {
         constexpr int ACT_C = decltype(act_c)::value;
         const int act_e = ACT_C >= 0 ? ACT_C : act;
@@ -195,7 +204,26 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
             const int ooff = first ? a.out0.off : a.out1.off;
             const int owidth = first ? a.out0.width : a.out1.width;
             const int cc = first ? c : c - a.split;
-            if (cc < owidth) {
+            const OutDesc& od = first ? a.out0 : a.out1;
+            if (od.p16.base != nullptr) {                         // block uniform: a P16 destination takes one (hi | lo) unit per lane
+                const int oct0 = (ooff + cc - 4 * lk) >> 3;       // first octet of the 16-channel tile
+                const int chunk = oct0 >> 2, rem = od.p16.octs - 4 * chunk;
+                const int rec = rem >= 4 ? 128 : 32 * rem;
+                char* base = od.p16.base + (long long)chunk * od.p16.plane + 128 + (oct0 & 3) * 32 + lk * 16;
+                const bool chan_ok = oct0 + (lk >> 1) < od.p16.octs;
+                static_for<0, G::MT>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    const long long p = pix0 + 32 * wave + 16 * m + lj;
+                    f32x4 v = acc[m][n] * inv + bv;
+                    v.x = activate1(v.x, av.x, act_e);
+                    v.y = activate1(v.y, av.y, act_e);
+                    v.z = activate1(v.z, av.z, act_e);
+                    v.w = activate1(v.w, av.w, act_e);
+                    if (ACT_C < 0) chk[m] = nonfinite_acc(chk[m], acc[m][n], zero);
+                    const u32x4 unit = p16_unit(v, m1, chk[m], zero2);
+                    if (p < npix && chan_ok) *reinterpret_cast<u32x4*>(base + (size_t)p * rec) = unit;
+                });
+            } else if (cc < owidth) {
                 static_for<0, G::MT>([&](auto m_) DCSCN_INL {
                     constexpr int m = decltype(m_)::value;
                     const long long p = pix0 + 32 * wave + 16 * m + lj;
@@ -205,7 +233,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
                     v.z = activate1(v.z, av.z, act_e);
                     v.w = activate1(v.w, av.w, act_e);
                     if (p < npix) {
-                        chk = nonfinite_acc(chk, acc[m][n], zero);
+                        chk[m] = nonfinite_acc(chk[m], acc[m][n], zero);
                         *reinterpret_cast<f32x4*>(optr + (size_t)p * ostride + ooff + cc) = v;
                     }
                 });
@@ -215,17 +243,27 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
     if (act == ACT_ALPHA) finish(std::integral_constant<int, ACT_ALPHA>{});
     else if (act == ACT_NONE) finish(std::integral_constant<int, ACT_NONE>{});
     else finish(std::integral_constant<int, -1>{});
-    if (chk != chk && a.redo) a.redo[blockIdx.x >> 1] = 1;     // the f32 kernel's unit is a block of 256 pixels
+    // the image of a pixel with a value beyond the f16 range goes to the float32 plan (exec.hip); columns past the end of the pixel list
+    // hold copies of the last pixel
+    static_for<0, G::MT>([&](auto m_) DCSCN_INL {
+        constexpr int m = decltype(m_)::value;
+        if (chk[m] != chk[m] && a.redo) {
+            long long p = pix0 + 32 * wave + 16 * m + lj;
+            p = p < npix ? p : npix - 1;
+            a.redo[0] = 1;
+            a.redo[1 + (int)(p / ((long long)a.H * a.W))] = 1;
+        }
+    });
 }
 
 // grid = (pixel blocks of 128, channel groups)
-template <int NT, bool MULTI = false, int S = 2, int WPS = 2>
+template <int NT, int SRC = 0, int S = 2, int WPS = 2>
 __global__ __launch_bounds__(256, WPS) void conv_nin_h(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const long long pix0 = (long long)blockIdx.x * NinHGeom<NT, S>::PIX;
     const int ntile = blockIdx.y;
-    if (ntile < a.n_full) conv_nin_h_body<NT, NT, MULTI, S>(a, smem, pix0, ntile);          // block uniform
-    else if constexpr (NT >= 2) conv_nin_h_body<NT, NT - 1, MULTI, S>(a, smem, pix0, ntile);
+    if (ntile < a.n_full) conv_nin_h_body<NT, NT, SRC, S>(a, smem, pix0, ntile);          // block uniform
+    else if constexpr (NT >= 2) conv_nin_h_body<NT, NT - 1, SRC, S>(a, smem, pix0, ntile);
 }
 
 }  // namespace dcscn

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, WPS) void conv_wino2(const ConvArgs a) {
     const int ntile = phase * S + (r >> 3);
     const int tile_id = q * 8 + (r & 7);
     if (tile_id >= a.N * a.tiles_y * a.tiles_x) return;
-    if (a.redo_check && a.redo[tile_id] == 0) return;          // fallback behind conv3_h: only the flagged pixel tiles
+    if (a.redo_check && (a.redo[0] == 0 || a.redo[1 + tile_id / (a.tiles_y * a.tiles_x)] == 0)) return;   // float32 plan: flagged images only
     if (ntile < a.n_full) conv_wino2_body<NT, NT, PF, ABL>(a, smem, tile_id, ntile);                 // block uniform
     else if constexpr (NT >= 2) conv_wino2_body<NT, NT - 1, PF, ABL>(a, smem, tile_id, ntile);
 }
@@ -401,7 +401,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino2_redo(const ConvArgs a) {
     const int n_tiles = a.N * a.tiles_y * a.tiles_x;
     const int t0 = blockIdx.x * 64;
     const int lane = threadIdx.x & 63;
-    const int flag = t0 + lane < n_tiles ? a.redo[t0 + lane] : 0;
+    if (a.redo[0] == 0) return;                               // no image of the pass was flagged (the normal case)
+    const int flag = t0 + lane < n_tiles ? a.redo[1 + (t0 + lane) / (a.tiles_y * a.tiles_x)] : 0;
     unsigned long long mask = __ballot(flag != 0);            // the same in all four waves
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)mask), hi = __builtin_amdgcn_readfirstlane((unsigned)(mask >> 32));
     mask = ((unsigned long long)hi << 32) | lo;

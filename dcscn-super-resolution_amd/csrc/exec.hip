@@ -11,23 +11,22 @@ namespace dcscn_impl {
 // of the new carve is enqueued there, behind an event wait on the previous forward (which may have run on another
 // stream and may still be in flight) -- nothing is cleared or re-carved underneath live kernels.
 int ensure_workspace(dcscn_ctx* h, int nb, int H, int W, hipStream_t stream) {
-    if (h->arena && nb <= h->lay_n && H == h->lay_h && W == h->lay_w) return DCSCN_OK;
-    std::vector<size_t> offsets(h->bufs.size());
+    const bool want16 = p16_active(h);
+    if (h->arena && nb <= h->lay_n && H == h->lay_h && W == h->lay_w && want16 == h->p16_now) return DCSCN_OK;
+    std::vector<size_t> offsets(h->bufs.size()), sizes(h->bufs.size());
     size_t total = 0;
     for (size_t i = 0; i < h->bufs.size(); ++i) {
         const WsBuf& b = h->bufs[i];
         offsets[i] = total;
-        const size_t bytes = (size_t)nb * H * b.res * W * b.res * b.stride * sizeof(float);
+        const long long npix = (long long)nb * H * b.res * W * b.res;
+        size_t bytes = (size_t)npix * b.stride * sizeof(float);
+        // a P16 tensor (p16.hpp) is never smaller than its float32 form: the float32 plan of a flagged image reuses the bytes
+        if (want16 && b.p16_ok && b.stride > 0) bytes = std::max(bytes, (size_t)p16_tensor_bytes(npix, b.octs));
+        sizes[i] = bytes;
         total += (bytes + 255) & ~(size_t)255;
     }
-    // redo flags of the split16 launches (split16.hpp): one per 256 pixels (conv_nin_h) / per 16x16 tile (conv3_h), cleared per pass
-    size_t redo_ints = 0;
-    for (Op& op : h->ops) {
-        if (!op.h16.on) continue;
-        const int Hr = H * op.res, Wr = W * op.res;
-        op.h16.redo_off = redo_ints;
-        redo_ints += op.shape.nin ? ((size_t)nb * Hr * Wr + 255) / 256 : (size_t)nb * ((Hr + 15) / 16) * ((Wr + 15) / 16);
-    }
+    // redo flags of a pass (split16.hpp): [0] = some image was flagged, [1 + image]; cleared per pass
+    const size_t redo_ints = 1 + (size_t)nb;
     h->redo_off = total;
     h->redo_ints = redo_ints;
     total += (redo_ints * sizeof(int32_t) + 255) & ~(size_t)255;
@@ -49,7 +48,14 @@ int ensure_workspace(dcscn_ctx* h, int nb, int H, int W, hipStream_t stream) {
     } else if (h->has_last && h->last_stream != stream) {
         HIP_TRY(h, hipStreamWaitEvent(stream, h->done_ev, 0));
     }
-    for (size_t i = 0; i < h->bufs.size(); ++i) h->bufs[i].offset = offsets[i];
+    for (size_t i = 0; i < h->bufs.size(); ++i) {
+        WsBuf& b = h->bufs[i];
+        b.offset = offsets[i];
+        b.bytes = sizes[i];
+        b.p16 = want16 && b.p16_ok && b.stride > 0;
+        b.plane = p16_plane_bytes((long long)nb * H * b.res * W * b.res);
+    }
+    h->p16_now = want16;
     // padding channels that no kernel writes (depth_to_space outputs with C % 4 != 0) must hold
     // finite values: clear the bytes of the new carve
     HIP_TRY(h, hipMemsetAsync(h->arena, 0, total, stream));
@@ -62,9 +68,37 @@ int ensure_workspace(dcscn_ctx* h, int nb, int H, int W, hipStream_t stream) {
 
 
 
+static P16Desc p16_desc(const dcscn_ctx* h, int id) {
+    const WsBuf& b = h->bufs[id];
+    return P16Desc{static_cast<char*>(h->arena) + b.offset, b.plane, b.octs, 0};
+}
+
+bool op_on_split16(const dcscn_ctx* h, const Op& op) {
+    return op.kind == OP_CONV && h->split16 && op.h16.on && (h->split16_mask & (op.shape.nin ? 2 : 1));
+}
+
+// conv3_h8 takes a 3x3 launch with two channel groups whose tensors are all P16 or all float32 (c3e_eligible without the pointers)
+bool op_takes_h8(const dcscn_ctx* h, const Op& op) {
+    if (!op_on_split16(h, op) || !h->conv3_h8 || op.shape.nin || op.fold_s > 0) return false;
+    ConvArgs a{};
+    a.n_full = op.h16.n_full; a.ps = op.ps; a.res = op.residual ? reinterpret_cast<const float*>(1) : nullptr; a.act = op.act; a.n_chunks = op.h16.n_chunks;
+    if (!c3e_eligible(op.h16.nt, a, op.h16.n_tiles)) return false;
+    const bool on16 = p16_active(h);                              // (what the next carve will hold; == h->p16_now inside a forward)
+    const bool in16 = on16 && op.h16.in16_ok;
+    bool all16 = true, any16 = false;
+    for (int k = 0; k < 2; ++k) {
+        if (k == 1 && op.split >= (1 << 29)) continue;
+        const bool o = on16 && op.out_buf[k] >= 0 && h->bufs[op.out_buf[k]].p16_ok && h->bufs[op.out_buf[k]].stride > 0;
+        all16 = all16 && o; any16 = any16 || o;
+    }
+    return in16 ? all16 : !any16;
+}
+
 int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, const float* x2, float* y,
-              hipStream_t stream) {
+              hipStream_t stream, bool redo) {
     const int Hr = H * op.res, Wr = W * op.res;
+    int32_t* const redo_flags = reinterpret_cast<int32_t*>(static_cast<char*>(h->arena) + h->redo_off);
+    if (redo && (op.kind == OP_TAIL || op.kind == OP_STREAM)) return fail(h, DCSCN_ERR_STATE, "float32 plan over a streamed launch");
     if (op.kind == OP_TAIL) {
         TailArgs a = op.tail;
         a.c2 = buf_ptr(h, op.in_buf);
@@ -144,6 +178,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.N = nb; a.H = Hr; a.W = Wr;
         a.out = buf_ptr(h, op.out_buf[0]);
         a.out_stride = pad4(op.cin);
+        a.redo = redo_flags; a.redo_check = redo ? 1 : 0;
         HIP_TRY(h, depthwise_launch(a, stream));
         return DCSCN_OK;
     }
@@ -162,6 +197,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.out_stride = 1;
         a.res = op.residual ? x2 : nullptr;
         a.res_stride = 1;
+        a.redo = redo_flags; a.redo_check = redo ? 1 : 0;
         HIP_TRY(h, cout1_launch(a, stream));
         return DCSCN_OK;
     }
@@ -177,6 +213,8 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.out.stride = h->bufs[op.out_buf[0]].stride;
         a.out.off = op.out_off[0];
         a.out.width = op.out_width[0];
+        if (!redo && h->bufs[op.out_buf[0]].p16) a.out.p16 = p16_desc(h, op.out_buf[0]);
+        a.redo = redo_flags; a.redo_check = redo ? 1 : 0;
         HIP_TRY(h, cin1_launch(a, stream));
         return DCSCN_OK;
     }
@@ -211,15 +249,24 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     a.dwk = op.dwk;
     a.fold = op.fold_s > 0 ? 1 : 0;
     a.srctab = op.multi.empty() ? nullptr : op.d_srctab;
-    if (h->split16 && op.h16.on && (h->split16_mask & (op.shape.nin ? 2 : 1))) {
-        // the contraction on the f16 matrix pipe; units with a non-finite output (an activation beyond the f16 range) raise their
-        // redo flag and the f32 launch below recomputes exactly those (it exits at once everywhere else)
+    a.redo = redo_flags;
+    if (!redo && op_on_split16(h, op)) {
+        // the contraction on the f16 matrix pipe; an image with a value beyond the f16 range (a non-finite accumulator, a P16 output
+        // that does not fit) raises its redo flag and is recomputed by the float32 plan behind the pass (run_forward)
         ConvArgs b = a;
         b.wpack16 = op.h16.d_w;
         b.inv_scale = op.h16.inv_scale;
         b.n_chunks = op.h16.n_chunks;
         b.n_full = op.h16.n_full;
-        b.redo = reinterpret_cast<int32_t*>(static_cast<char*>(h->arena) + h->redo_off) + op.h16.redo_off;
+        if (h->p16_now && op.h16.in16_ok) {                   // P16 sources (p16.hpp)
+            b.in16 = p16_desc(h, op.multi.empty() ? op.in_buf : op.multi[0].first);
+            b.in = nullptr;
+            if (op.shape.nin) b.srctab = op.h16.d_tab16;
+        }
+        for (int i = 0; i < 2; ++i) {
+            OutDesc& o = i == 0 ? b.out0 : b.out1;
+            if (op.out_buf[i] >= 0 && h->bufs[op.out_buf[i]].p16) o.p16 = p16_desc(h, op.out_buf[i]);
+        }
         if (op.shape.nin) HIP_TRY(h, nin_h_launch(op.h16.nt, b, op.h16.n_tiles, stream));
         else if (op.fold_s > 0) {
             b.bias = op.h16.d_bias;
@@ -228,12 +275,12 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
             b.bias = op.h16.d_bias;
             b.tail_octs = op.h16.tail_octs;
             b.alpha = op.h16.d_alpha;
-            if (h->conv3_h8 && c3e_eligible(op.h16.nt, b, op.h16.n_tiles)) HIP_TRY(h, c3e_launch(op.h16.nt, b, op.h16.n_tiles, h->n_cus, stream));
+            if (op_takes_h8(h, op)) HIP_TRY(h, c3e_launch(op.h16.nt, b, op.h16.n_tiles, h->n_cus, stream));
             else HIP_TRY(h, c3h_launch(op.h16.nt, b, op.h16.n_tiles, stream));
         }
-        a.redo = b.redo;
-        a.redo_check = 1;
+        return DCSCN_OK;
     }
+    a.redo_check = redo ? 1 : 0;
     if (op.shape.nin) HIP_TRY(h, nin_launch(op.shape.nt, a, op.n_tiles, stream));
     else if (op.shape.wino) HIP_TRY(h, wino_launch(op.shape.nt, a, op.n_tiles, stream));
     else HIP_TRY(h, conv_launch(op.shape, a, op.n_tiles, stream));
@@ -342,9 +389,15 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     const int64_t per_image = (int64_t)H * W;
     int64_t ws_per_lr_pixel = 0;      // workspace bytes per LR pixel
     for (const WsBuf& b : h->bufs) ws_per_lr_pixel += (int64_t)b.res * b.res * b.stride * (int64_t)sizeof(float);
-    const int64_t pass_pixels = std::min<int64_t>(h->sub_batch_pixels, h->workspace_budget / std::max<int64_t>(ws_per_lr_pixel, 1));
+    int64_t pass_pixels = std::min<int64_t>(h->sub_batch_pixels, h->workspace_budget / std::max<int64_t>(ws_per_lr_pixel, 1));
     // sub_batch_pixels is a soft knob (a pass holds at least one image); the workspace budget is the hard one
-    const int64_t budget_pixels = h->workspace_budget / std::max<int64_t>(ws_per_lr_pixel, 1);
+    int64_t budget_pixels = h->workspace_budget / std::max<int64_t>(ws_per_lr_pixel, 1);
+    if (p16_active(h)) {
+        // record offsets inside a P16 plane are 32-bit (kernels.h: kP16MaxPixels): bounds the pixels of a pass at the tensors' resolution
+        const int64_t cap = kP16MaxPixels / ((int64_t)h->p16_max_res * h->p16_max_res);
+        pass_pixels = std::min(pass_pixels, cap);
+        budget_pixels = std::min(budget_pixels, cap);
+    }
     // two forwards of one handle share the arena and the tile staging buffers: a forward on another stream than the previous
     // one waits for it -- before anything of this forward is enqueued, the gathers of run_tiled included
     if (h->has_last && h->last_stream != stream) HIP_TRY(h, hipStreamWaitEvent(stream, h->done_ev, 0));
@@ -360,17 +413,53 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         // the multi-source tables hold arena addresses: refill them behind the re-carve, on the launch stream
         for (Op& op : h->ops) {
             if (op.multi.empty()) continue;
+            // float32 form: one entry per channel quad of the pad-8 virtual K axis (densify_features); padding quads point at readable
+            // memory with stride 0 (conv_nin_h fetches every quad; their filter rows are zero)
+            const unsigned long long pad_ptr = (unsigned long long)(uintptr_t)buf_ptr(h, op.multi[0].first);
             size_t q = 0;
             for (const auto& sg : op.multi) {
                 const char* base = reinterpret_cast<const char*>(buf_ptr(h, sg.first));
                 const unsigned stride = (unsigned)(h->bufs[sg.first].stride * sizeof(float));
-                for (int c4 = 0; c4 < sg.second / 4 && q < op.h_srctab.size(); ++c4, ++q)
-                    op.h_srctab[q] = NinSrcQuad{(unsigned long long)(uintptr_t)(base + 16 * c4), stride, 1u};
+                for (int c4 = 0; c4 < ((sg.second + 7) & ~7) / 4 && q < op.h_srctab.size(); ++c4, ++q)
+                    op.h_srctab[q] = c4 < sg.second / 4 ? NinSrcQuad{(unsigned long long)(uintptr_t)(base + 16 * c4), stride, 1u} : NinSrcQuad{pad_ptr, 0, 0};
             }
-            // padding quads point at readable memory with stride 0 (conv_nin_h fetches every quad; their filter rows are zero)
-            const unsigned long long pad_ptr = (unsigned long long)(uintptr_t)buf_ptr(h, op.multi[0].first);
             for (; q < op.h_srctab.size(); ++q) op.h_srctab[q] = NinSrcQuad{pad_ptr, 0, 0};
             HIP_TRY(h, hipMemcpyAsync(op.d_srctab, op.h_srctab.data(), op.h_srctab.size() * sizeof(NinSrcQuad), hipMemcpyHostToDevice, stream));
+        }
+        // P16 form of the 1x1 GEMMs' K axis (conv_nin_h.hpp, SRC = 2): one entry per channel OCTET = {the octet's hi unit in the record of
+        // pixel 0, record bytes}; entries past the last octet read a zero record with stride 0
+        for (Op& op : h->ops) {
+            if (!op.h16.d_tab16 || !h->p16_now || !op.h16.in16_ok) continue;
+            std::vector<std::pair<int, int>> srcs = op.multi;
+            if (srcs.empty()) srcs.push_back({op.in_buf, op.cin_phys});
+            const unsigned long long zero_rec = (unsigned long long)(uintptr_t)buf_ptr(h, srcs[0].first);
+            size_t q = 0;
+            for (const auto& sg : srcs) {
+                const WsBuf& wb = h->bufs[sg.first];
+                const char* base = reinterpret_cast<const char*>(buf_ptr(h, sg.first));
+                for (int o = 0; o < wb.octs && q < op.h16.h_tab16.size(); ++o, ++q)
+                    op.h16.h_tab16[q] = NinSrcQuad{(unsigned long long)(uintptr_t)(base + (long long)(o >> 2) * wb.plane + 128 + (o & 3) * 32),
+                                                   (unsigned)p16_rec_bytes(wb.octs, o >> 2), 1u};
+            }
+            for (; q < op.h16.h_tab16.size(); ++q) op.h16.h_tab16[q] = NinSrcQuad{zero_rec, 0, 0};
+            HIP_TRY(h, hipMemcpyAsync(op.h16.d_tab16, op.h16.h_tab16.data(), op.h16.h_tab16.size() * sizeof(NinSrcQuad), hipMemcpyHostToDevice, stream));
+        }
+        // the zero records of the P16 planes: re-cleared at the start of every pass (the float32 plan of a flagged image writes float32
+        // tensors over the same bytes)
+        h->h_zrec.clear();
+        for (const WsBuf& wb : h->bufs)
+            if (wb.p16)
+                for (int c = 0; c < (wb.octs + 3) / 4; ++c) h->h_zrec.push_back((unsigned long long)(uintptr_t)(static_cast<char*>(h->arena) + wb.offset + (long long)c * wb.plane));
+        if (!h->h_zrec.empty()) {
+            if (h->h_zrec.size() > h->zrec_cap) {
+                HIP_TRY(h, hipStreamSynchronize(stream));
+                if (h->d_zrec) HIP_TRY(h, hipFree(h->d_zrec));
+                h->d_zrec = nullptr;
+                h->zrec_cap = 0;
+                HIP_TRY(h, hipMalloc((void**)&h->d_zrec, h->h_zrec.size() * 2 * sizeof(unsigned long long)));
+                h->zrec_cap = h->h_zrec.size() * 2;
+            }
+            HIP_TRY(h, hipMemcpyAsync(h->d_zrec, h->h_zrec.data(), h->h_zrec.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
         }
         h->tables_gen = h->carve_gen;
     }
@@ -381,15 +470,21 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     size_t ev_base = 0;
     if (h->profile) {
         ev_base = h->ev_used;
-        const size_t need = ev_base + (size_t)batches * nops * 2;
+        const size_t need = ev_base + (size_t)batches * (nops + 1) * 2;      // one pair per launch, one per pass around its float32 plan
         while (h->ev.size() < need) {
             hipEvent_t e;
             HIP_TRY(h, hipEventCreate(&e));
             h->ev.push_back(e);
         }
-        h->ev_used = need;
         h->ev_forwards += 1;
     }
+    // (pairs are handed out in launch order; ev_op remembers which launch a pair belongs to: nops = the float32 plan of a pass)
+    auto ev_pair = [&](int op_index) -> size_t {
+        const size_t at = h->ev_used;
+        h->ev_used += 2;
+        h->ev_op.push_back(op_index);
+        return at;
+    };
     // graph replay (option "graph_replay"): the launch sequence below depends only on the arguments and on the arena's carve, so a
     // forward whose arguments repeat is captured the second time it is seen and replayed afterwards
     dcscn_ctx::GraphKey gkey;
@@ -397,8 +492,9 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     gkey.split16 = h->split16 ? h->split16_mask : 0;
     gkey.nb = nb;                                        // the pass size (sub_batch_pixels / budget) shapes the launch sequence too
     gkey.h8 = h->conv3_h8 ? 1 : 0;
+    gkey.p16 = h->p16_now ? 1 : 0;
     gkey.carve = (unsigned long long)h->carve_gen;
-    const bool graphs = h->graph_replay && !h->profile;
+    const bool graphs = h->graph_replay && !h->profile && !h->debug_digest && !h->debug_poison;   // (debug launches allocate / are not part of the key)
     bool capturing = false;
     if (graphs && h->graph_exec && gkey == h->graph_key) {
         HIP_TRY(h, hipGraphLaunch(h->graph_exec, stream));
@@ -430,22 +526,26 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         const float* xb = x + (size_t)b0 * H * W;
         const float* x2b = x2 + (size_t)b0 * H * s * W * s;
         float* yb = y + (size_t)b0 * H * s * W * s;
-        if (h->split16 && h->redo_ints) {
-            const hipError_t me = hipMemsetAsync(static_cast<char*>(h->arena) + h->redo_off, 0, h->redo_ints * sizeof(int32_t), stream);
+        bool any_h16 = false;
+        for (const Op& op : h->ops) any_h16 = any_h16 || op_on_split16(h, op);
+        if (any_h16) {                                   // redo flags and the P16 planes' zero records
+            const hipError_t me = pass_begin_launch(reinterpret_cast<int32_t*>(static_cast<char*>(h->arena) + h->redo_off), (int)h->redo_ints,
+                                                    h->p16_now ? h->d_zrec : nullptr, h->p16_now ? (int)h->h_zrec.size() : 0, stream);
             if (me != hipSuccess) {
                 abandon_capture();
                 HIP_TRY(h, me);
             }
         }
         for (int i = 0; i < nops; ++i) {
-            if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[ev_base + ((size_t)b * nops + i) * 2], stream));
+            size_t evi = 0;
+            if (h->profile) { evi = ev_pair(i); HIP_TRY(h, hipEventRecord(h->ev[evi], stream)); }
             if (h->debug_poison) HIP_TRY(h, debug_poison_launch(h->debug_poison, stream));
             rc = launch_op(h, h->ops[i], cnt, H, W, xb, x2b, yb, stream);
             if (rc) {
                 abandon_capture();
                 return rc;
             }
-            if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[ev_base + ((size_t)b * nops + i) * 2 + 1], stream));
+            if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[evi + 1], stream));
             if (h->debug_digest) {                        // checksum of the buffer(s) this launch writes
                 const Op& op = h->ops[i];
                 for (int k = 0; k < 2; ++k) {
@@ -453,12 +553,27 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
                     if (k == 1 && idx == op.out_buf[0]) break;
                     if (idx >= 0) {
                         const WsBuf& wb = h->bufs[idx];
-                        HIP_TRY(h, debug_digest_launch(static_cast<const char*>(h->arena) + wb.offset, (size_t)cnt * H * wb.res * W * wb.res * wb.stride, h->d_digest + i, stream));
+                        HIP_TRY(h, debug_digest_launch(static_cast<const char*>(h->arena) + wb.offset, wb.p16 ? wb.bytes / 4 : (size_t)cnt * H * wb.res * W * wb.res * wb.stride, h->d_digest + i, stream));
                     } else if (idx == EXT_Y) {
                         HIP_TRY(h, debug_digest_launch(yb, (size_t)cnt * H * s * W * s, h->d_digest + i, stream));
                     }
                 }
             }
+        }
+        // the float32 plan: every launch again on its float32 kernel, gated by the pass's redo flags -- computes the images a split16 launch
+        // flagged (a value beyond the f16 range) from the first layer on, as float32 tensors in the same workspace; exits at once otherwise
+        if (any_h16) {
+            size_t evi = 0;
+            if (h->profile) { evi = ev_pair(nops); HIP_TRY(h, hipEventRecord(h->ev[evi], stream)); }
+            for (int i = 0; i < nops; ++i) {
+                if (!h->ops[i].h16.rerun) continue;           // upstream of every split16 launch: its float32 outputs stand
+                rc = launch_op(h, h->ops[i], cnt, H, W, xb, x2b, yb, stream, true);
+                if (rc) {
+                    abandon_capture();
+                    return rc;
+                }
+            }
+            if (h->profile) HIP_TRY(h, hipEventRecord(h->ev[evi + 1], stream));
         }
         if (h->debug_digest) HIP_TRY(h, debug_digest_launch(yb, (size_t)cnt * H * s * W * s, h->d_digest + nops, stream));
     }

@@ -283,12 +283,14 @@ int build_graph(dcscn_ctx* h) {
 
     filter_schedule(c.layers, c.filters, c.min_filters, c.filters_decay_gamma, h->sched);
     std::vector<int> slice_off(c.layers);
-    int concat_stride = 0, total = 0;
+    int concat_stride = 0, total = 0, concat_data = 0;     // concat_data: channels that hold data (each layer padded to 4): the bytes accounting
     for (int i = 0; i < c.layers; ++i) {
         if (h->sched[i] <= 0) return fail(h, DCSCN_ERR_INVALID_ARG, "feature layer %d has %d filters", i + 1, h->sched[i]);
         slice_off[i] = concat_stride;
-        concat_stride += pad4(h->sched[i]);
+        concat_stride += (h->sched[i] + 7) & ~7;               // slices start on 8-channel boundaries (r05): a channel octet of the K axis of A1 || B1
+                                                               // belongs to ONE layer, with or without densify_features, float32 or P16 (p16.hpp)
         total += h->sched[i];
+        concat_data += pad4(h->sched[i]);
     }
     const int concat = new_buf(h, concat_stride, 1);
     h->concat_buf = concat;
@@ -352,7 +354,7 @@ int build_graph(dcscn_ctx* h) {
             f.out_buf[0] = t1; f.out_off[0] = 0; f.out_width[0] = pad4(nb);
             f.out_buf[1] = t2; f.out_off[1] = pad4(nb); f.out_width[1] = pad4(na);
             f.macs = a1.macs + b1.macs;
-            f.bytes = 4 * (int64_t)concat_stride + 4 * (pad4(na) + pad4(nb));
+            f.bytes = 4 * (int64_t)concat_data + 4 * (pad4(na) + pad4(nb));
             h->ops.push_back(f);
         }
         Dst d2;
@@ -667,7 +669,9 @@ void fuse_tail_stream(dcscn_ctx* h) {
 // same time).  When every consumer of the whole concat is a conv_nin launch (A1 || B1, or the non-NIN "C"
 // layer), this pass gives each feature layer its own dense [n, H, W, pad4(C_i)] buffer and hands the consumers the list
 // of buffers: conv_nin walks them through a per-quad source table (conv_nin.hpp: MULTI).  The virtual channel order is
-// unchanged, so chan_map and the packed filters stay as they are.
+// unchanged, so chan_map and the packed filters stay as they are.  (The concat's slices start on 8-channel boundaries -- build_graph --
+// so the table holds a padding quad behind a layer whose quad count is odd: a channel octet of the K axis belongs to one layer, which is
+// what lets the same filter image serve the float32 buffers and their P16 form: a 16-byte unit of p16.hpp holds 8 channels of ONE tensor.)
 void densify_features(dcscn_ctx* h) {
     if (!h->dense_features || h->concat_buf < 0) return;
     const int cat = h->concat_buf;
@@ -701,6 +705,93 @@ void densify_features(dcscn_ctx* h) {
     bool used = false;
     for (const Op& o : h->ops) used = used || (o.multi.empty() && o.in_buf == cat) || o.out_buf[0] == cat || o.out_buf[1] == cat;
     if (!used) h->bufs[cat].stride = 0;                         // the concat tensor no longer exists
+}
+
+// ---- P16 tensors (p16.hpp) ----------------------------------------------------------------------------
+// A workspace tensor is kept in the pre-split form when EVERY launch that writes it can store (hi | lo) units -- conv_cin1, conv3_h,
+// conv3_h8, conv_nin_h with a plain NHWC destination on a 16-channel boundary -- and EVERY launch that reads it is a split16 kernel
+// reading the whole tensor from channel 0 in its natural channel order (conv3_h / conv3_h8 / conv5_h; conv_nin_h when ALL its sources
+// qualify).  Fixed point over the launch list; runs after finalize_op (it needs to know which launches have a split16 variant).
+void plan_p16(dcscn_ctx* h) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+    const size_t nbuf = h->bufs.size();
+    std::vector<char> ok(nbuf, 0), written(nbuf, 0), read(nbuf, 0);
+    for (size_t b = 0; b < nbuf; ++b) ok[b] = h->bufs[b].stride > 0;
+    const bool mixed = false;
+    auto inputs = [&](const Op& op) {
+        std::vector<int> v;
+        if (!op.multi.empty()) for (const auto& m : op.multi) v.push_back(m.first);
+        else if (op.in_buf >= 0) v.push_back(op.in_buf);
+        return v;
+    };
+    auto can_read = [&](const Op& op) {
+        if (op.kind != OP_CONV || !op.h16.on || op.dwk != 0 || op.in_stride_override > 0) return false;
+        if (!op.multi.empty()) return op.shape.nin != 0;          // (the pad-8 virtual K axis of densify_features)
+        if (op.in_buf < 0 || op.in_off != 0 || op.cin_phys != h->bufs[op.in_buf].stride) return false;
+        for (size_t i = 0; i < op.chan_map.size(); ++i)
+            if (op.chan_map[i] != (int)i) return false;
+        return true;
+    };
+    auto can_write = [&](const Op& op, int k) {
+        if (op.kind == OP_CIN1) return k == 0 && op.out_off[0] == 0;
+        if (op.kind != OP_CONV || !op.h16.on || op.fold_s > 0 || op.ps != 1 || op.residual || op.dwk != 0) return false;
+        if (op.out_off[k] % 16 != 0) return false;
+        return k == 0 || op.split % 16 == 0;
+    };
+    for (bool changed = !mixed; changed;) {
+        changed = false;
+        for (const Op& op : h->ops) {
+            const std::vector<int> in = inputs(op);
+            bool all = can_read(op);
+            for (int b : in) all = all && ok[b];
+            if (!all)
+                for (int b : in)
+                    if (ok[b]) { ok[b] = 0; changed = true; }
+            for (int k = 0; k < 2; ++k) {
+                const int b = op.out_buf[k];
+                if (b < 0 || (k == 1 && op.split >= (1 << 29))) continue;
+                if (ok[b] && !can_write(op, k)) { ok[b] = 0; changed = true; }
+            }
+        }
+    }
+    for (const Op& op : h->ops) {
+        for (int b : inputs(op)) read[b] = 1;
+        for (int k = 0; k < 2; ++k)
+            if (op.out_buf[k] >= 0 && !(k == 1 && op.split >= (1 << 29))) written[op.out_buf[k]] = 1;
+    }
+    h->any_p16 = false;
+    h->p16_max_res = 1;
+    for (size_t b = 0; b < nbuf; ++b) {
+        WsBuf& wb = h->bufs[b];
+        wb.p16_ok = !mixed && ok[b] && written[b] && read[b];
+        wb.octs = (wb.stride + 7) / 8;
+        if (wb.p16_ok) { h->any_p16 = true; h->p16_max_res = std::max(h->p16_max_res, wb.res); }
+    }
+    for (Op& op : h->ops) {
+        const std::vector<int> in = inputs(op);
+        bool all = !in.empty() && can_read(op);
+        for (int b : in) all = all && h->bufs[b].p16_ok;
+        op.h16.in16_ok = all;
+    }
+    // the float32 plan of a flagged image (exec.hip: run_forward): every launch downstream of a split16 launch or of a P16 tensor
+    std::vector<char> dirty(nbuf, 0);
+    bool streamed = false;                                        // the streamed kernels cannot be gated per image
+    for (Op& op : h->ops) {
+        bool r = op.kind == OP_CONV && op.h16.on;
+        for (int b : inputs(op)) r = r || dirty[b];
+        for (int k = 0; k < 2; ++k)
+            if (op.out_buf[k] >= 0 && !(k == 1 && op.split >= (1 << 29))) r = r || h->bufs[op.out_buf[k]].p16_ok;
+        op.h16.rerun = r;
+        if (r) {
+            streamed = streamed || op.kind == OP_STREAM || op.kind == OP_TAIL;
+            for (int k = 0; k < 2; ++k)
+                if (op.out_buf[k] >= 0) dirty[op.out_buf[k]] = 1;
+        }
+    }
+    if (!streamed) return;
+    // a streamed launch behind a split16 launch: no float32 plan can be gated there -- the graph stays on the float32 kernels
+    for (Op& op : h->ops) op.h16.on = false;
+    }
 }
 
 }  // namespace dcscn_impl

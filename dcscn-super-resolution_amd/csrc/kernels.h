@@ -81,10 +81,10 @@ struct ConvArgs {
     // split16 kernels (split16.hpp: f32-accurate contraction on the f16 matrix pipe)
     const void* wpack16;      // filters as f16 (hi, lo) fragments (split16_pack.hpp), scaled by 2^e
     float inv_scale;          // 2^-e
-    int32_t* redo;            // one flag per unit (conv_nin: block of 256 pixels; 3x3: 16x16 pixel tile): a split16 kernel sets
-                              // redo[unit] = 1 when an output of the unit is not finite (an activation beyond the f16 range)
+    int32_t* redo;            // [0] = pass flag, [1 + image]: a split16 kernel raises both when an image cannot stay on the f16 pipe (a
+                              // non-finite accumulator = an input beyond the f16 range, or a P16 output beyond it)
     int32_t tail_octs;        // conv3_h: 0, or 1 / 2 / 3 = channel octets of the packed last chunk (c3h_tail_octs)
-    int32_t redo_check;       // f32 kernels: 1 = run only the units whose flag is set (the launch behind a split16 kernel)
+    int32_t redo_check;       // float32 kernels: 1 = the float32 plan behind a split16 pass -- only the units of flagged images are computed
     int32_t nt_pack;          // conv3_h8: channel tiles per group in the wpack16 image (the half of a workgroup may take fewer)
     int32_t* work;            // conv3_hp (persistent workgroups): the launch's item counters, one per XCD at 64-byte spacing (8 x 16 ints), zero when the launch starts
 };
@@ -262,7 +262,9 @@ struct Cin1Args {
     int32_t ks;
     int32_t N, H, W;
     int32_t cs;               // stored channels (multiple of 4)
-    OutDesc out;
+    OutDesc out;              // (out.p16.base != nullptr: a P16 tensor, p16.hpp)
+    int32_t* redo;            // [0] pass flag, [1 + image]: raised when a P16 output leaves the f16 range; read when redo_check is set
+    int32_t redo_check;       // 1: float32 plan behind a split16 pass -- only the flagged images are computed
 };
 hipError_t cin1_launch(const Cin1Args& a, hipStream_t stream);
 
@@ -277,6 +279,7 @@ struct Cout1Args {
     int32_t N, H, W;
     float* out; int32_t out_stride;
     const float* res; int32_t res_stride;   // optional residual, same pixel indexing as out
+    const int32_t* redo; int32_t redo_check;   // 1: float32 plan behind a split16 pass -- only images with redo[1 + image] set (redo[0]: any)
 };
 hipError_t cout1_launch(const Cout1Args& a, hipStream_t stream);
 
@@ -288,8 +291,12 @@ struct DwArgs {
     int32_t ks, cin, cout_phys;
     int32_t N, H, W;
     float* out; int32_t out_stride;   // writes channels [0, cout_phys): logical then zero padding
+    const int32_t* redo; int32_t redo_check;   // as Cout1Args
 };
 hipError_t depthwise_launch(const DwArgs& a, hipStream_t stream);
+// start of a pass that runs split16 launches: clears the n redo flags and the 128-byte zero records of the P16 planes (p16.hpp; zrec =
+// device array of their nz addresses, may be null)
+hipError_t pass_begin_launch(int32_t* redo, int n, const unsigned long long* zrec, int nz, hipStream_t stream);
 // debug (option "debug_poison"): fill the LDS (what & 1) / the vector registers (what & 2) of every CU with NaN patterns
 hipError_t debug_poison_launch(int what, hipStream_t stream);
 // debug (option "debug_digest"): *out += position-weighted checksum of n 32-bit words

@@ -12,6 +12,7 @@
 // padded to a multiple of 4 channels (padding lanes hold finite values and meet zero weights), so all
 // global traffic is 16-byte vectors.
 #include "conv_variants.hpp"
+#include "p16.hpp"
 
 namespace dcscn {
 
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256) void conv_cin1(const Cin1Args a, int tpp_log2)
     const int img = bid / tiles_y;
     const int y0 = ty * T, x0 = tx * T;
     const int tid = threadIdx.x;
+    if (a.redo_check && (a.redo[0] == 0 || a.redo[1 + img] == 0)) return;   // float32 plan behind a split16 pass: flagged images only
 
     const float* xin = a.x + (size_t)img * a.H * a.W;
     for (int i = tid; i < HT * HT; i += 256) {
@@ -88,6 +90,10 @@ __global__ __launch_bounds__(256) void conv_cin1(const Cin1Args a, int tpp_log2)
     const int cl = tid & (tpp - 1);
     const int pl = tid >> tpp_log2;
     const int ppi = 256 >> tpp_log2;   // pixels per iteration
+    const bool o16 = a.out.p16.base != nullptr;   // P16 destination (p16.hpp): the (hi, lo) halves of the quad, 8 bytes each
+    const float m1 = opaque_minus_one();
+    const h2 zero2 = p16_opaque_zero2();
+    float chk = 0.0f;
     for (int c4 = cl; c4 < c4n; c4 += tpp) {
         f32x4 wr[TAPS];
 #pragma unroll
@@ -111,9 +117,35 @@ __global__ __launch_bounds__(256) void conv_cin1(const Cin1Args a, int tpp_log2)
             v.z = activate1(v.z, av.z, a.act);
             v.w = activate1(v.w, av.w, a.act);
             const size_t pix = ((size_t)img * a.H + gy) * a.W + gx;
+            if (o16) {
+                const int oct = c4 >> 1, chunk = oct >> 2, rem = a.out.p16.octs - 4 * chunk;
+                const int rec = rem >= 4 ? 128 : 32 * rem;
+                h4 hi, lo;
+                split4(v, m1, hi, lo);
+                const u32x2 hu = __builtin_bit_cast(u32x2, hi), lu = __builtin_bit_cast(u32x2, lo);
+                chk = p16_check(p16_check(chk, hu.x, zero2), hu.y, zero2);
+                char* dst = a.out.p16.base + (long long)chunk * a.out.p16.plane + 128 + pix * rec + (oct & 3) * 32 + (c4 & 1) * 8;
+                *reinterpret_cast<u32x2*>(dst) = hu;
+                *reinterpret_cast<u32x2*>(dst + 16) = lu;
+            } else
             *reinterpret_cast<f32x4*>(a.out.ptr + pix * a.out.stride + a.out.off + 4 * c4) = v;
         }
+        // a P16 tensor holds whole octets: an odd quad count leaves the upper half of the last octet to be written as zeros
+        if (o16 && c4 == c4n - 1 && (c4n & 1)) {
+            for (int p = pl; p < T * T; p += ppi) {
+                const int py = p >> 4, px = p & 15;
+                const int gy = y0 + py, gx = x0 + px;
+                if (gy >= a.H || gx >= a.W) continue;
+                const size_t pix = ((size_t)img * a.H + gy) * a.W + gx;
+                const int oct = c4 >> 1, chunk = oct >> 2, rem = a.out.p16.octs - 4 * chunk;
+                const int rec = rem >= 4 ? 128 : 32 * rem;
+                char* dst = a.out.p16.base + (long long)chunk * a.out.p16.plane + 128 + pix * rec + (oct & 3) * 32 + 8;
+                *reinterpret_cast<u32x2*>(dst) = u32x2{0u, 0u};
+                *reinterpret_cast<u32x2*>(dst + 16) = u32x2{0u, 0u};
+            }
+        }
     }
+    if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + img] = 1; }     // an output beyond the f16 range: the image goes to the float32 plan
 }
 
 hipError_t cin1_launch(const Cin1Args& a, hipStream_t stream) {
@@ -158,6 +190,7 @@ __global__ __launch_bounds__(256) void conv_cout1(const Cout1Args a) {
     const int img = bid / tiles_y;
     const int y0 = ty * T, x0 = tx * T;
     const int tid = threadIdx.x;
+    if (a.redo_check && (a.redo[0] == 0 || a.redo[1 + img] == 0)) return;   // float32 plan behind a split16 pass: flagged images only
 
     for (int i = tid; i < TAPS * a.cin_phys; i += 256) ws[i] = a.w[i];
     __syncthreads();
@@ -238,6 +271,7 @@ __global__ __launch_bounds__(256) void depthwise_kernel(const DwArgs a, long lon
     if (idx >= total) return;
     const int c = (int)(idx % a.cout_phys);
     const long long pix = idx / a.cout_phys;
+    if (a.redo_check && (a.redo[0] == 0 || a.redo[1 + pix / ((long long)a.H * a.W)] == 0)) return;   // float32 plan: flagged images only
     float out = 0.0f;
     if (c < a.cin) {
         const int x = (int)(pix % a.W);
@@ -270,6 +304,17 @@ hipError_t depthwise_launch(const DwArgs& a, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------
 // debug: poison what a kernel must not depend on (LDS and register contents left by whoever ran before)
 // ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pass_begin_kernel(int32_t* redo, int n, const unsigned long long* zrec, int nz) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) redo[i] = 0;
+    if (i < nz * 8) reinterpret_cast<u32x4*>((uintptr_t)zrec[i >> 3])[i & 7] = u32x4{0u, 0u, 0u, 0u};
+}
+hipError_t pass_begin_launch(int32_t* redo, int n, const unsigned long long* zrec, int nz, hipStream_t stream) {
+    const int work = n > nz * 8 ? n : nz * 8;
+    hipLaunchKernelGGL(pass_begin_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, redo, n, zrec, zrec ? nz : 0);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void poison_lds(int bytes) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     for (int i = threadIdx.x; i < bytes / 4; i += 256) smem[i] = __uint_as_float(0x7fc0dea0u + (i & 15));

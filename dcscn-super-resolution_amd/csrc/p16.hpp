@@ -49,7 +49,7 @@ __device__ __forceinline__ u32x4 p16_unit(const f32x4 v, float m1, float& chk, h
 }
 
 // float32 NHWC -> P16 (tests, the harness, and tensors a float32 kernel produced for a split16 consumer); one thread per (pixel, octet)
-__global__ void p16_pack_kernel(const float* in, int in_stride, int channels, long long npix, P16Desc d) {
+static __global__ void p16_pack_kernel(const float* in, int in_stride, int channels, long long npix, P16Desc d) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix * d.octs) return;
     const long long p = idx / d.octs;
@@ -70,7 +70,7 @@ __global__ void p16_pack_kernel(const float* in, int in_stride, int channels, lo
 }
 
 // P16 -> two float32 NHWC tensors of the stored pieces (hi, lo as floats): bit-level comparison of a P16 tensor with split(x)
-__global__ void p16_unpack_kernel(P16Desc d, long long npix, float* hi_out, float* lo_out, int out_stride) {
+static __global__ void p16_unpack_kernel(P16Desc d, long long npix, float* hi_out, float* lo_out, int out_stride) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= npix * d.octs) return;
     const long long p = idx / d.octs;

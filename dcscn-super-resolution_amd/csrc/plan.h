@@ -40,6 +40,12 @@ struct WsBuf {
     int stride = 0;       // floats per pixel
     int res = 1;          // pixels per LR pixel along one axis
     size_t offset = 0;    // byte offset inside the arena for the current layout
+    // P16 (kernels.h: P16Desc; graph.hip: plan_p16): every producer can store and every consumer can read the pre-split form, so the
+    // tensor lives in it while the split16 launches run; `p16` = it does in the current carve (options split16 / p16)
+    bool p16_ok = false, p16 = false;
+    int octs = 0;         // channel octets = ceil(stride / 8)
+    long long plane = 0;  // bytes between chunk planes in the current carve
+    size_t bytes = 0;     // bytes of the tensor in the current carve
 };
 
 // one source block of a launch's filter matrix: conv channels [dst, dst + cout) come from `w`
@@ -109,7 +115,11 @@ struct Op {
         float* d_bias = nullptr;                  // conv3_h: bias / slope in ITS padded group layout (conv_nin_h shares the f32 launch's)
         float* d_alpha = nullptr;
         int tail_octs = 0;                        // conv3_h: channel octets of the packed last chunk (kernels.h: c3h_tail_octs)
-        size_t redo_off = 0;                      // first flag of the op among the pass's redo flags (ensure_workspace)
+        bool rerun = false;                       // plan_p16: the launch belongs to the float32 plan of a flagged image (it is a split16 launch,
+                                                  // writes a P16 tensor, or reads what such a launch writes); set for any kind of op
+        bool in16_ok = false;                     // plan_p16: all the op's inputs are P16-capable tensors and its split16 kernel can read them
+        std::vector<NinSrcQuad> h_tab16;          // conv_nin_h with P16 sources: one entry per channel octet of the K axis (refilled per carve)
+        NinSrcQuad* d_tab16 = nullptr;
     } h16;
 };
 
@@ -175,11 +185,11 @@ struct dcscn_ctx {
     struct GraphKey {
         const void *x = nullptr, *x2 = nullptr, *y = nullptr;
         void* stream = nullptr;
-        int n = 0, H = 0, W = 0, split16 = 0, nb = 0, h8 = 0;
+        int n = 0, H = 0, W = 0, split16 = 0, nb = 0, h8 = 0, p16 = 0;
         unsigned long long carve = 0;
         bool operator==(const GraphKey& o) const {
             return x == o.x && x2 == o.x2 && y == o.y && stream == o.stream && n == o.n && H == o.H && W == o.W && split16 == o.split16 && nb == o.nb &&
-                   h8 == o.h8 && carve == o.carve;
+                   h8 == o.h8 && p16 == o.p16 && carve == o.carve;
         }
     };
     GraphKey graph_seen, graph_key;          // the previous forward's arguments; the arguments graph_exec was captured with
@@ -189,7 +199,11 @@ struct dcscn_ctx {
     bool stream_features = true;             // separable narrow nets: CNN1 .. B2 as one row-streamed launch (fuse_feat_stream)
     int split16_mask = 3;                    // debugging aid (option "split16" 2 / 3): bit 0 = conv3_h, bit 1 = conv_nin_h
     bool split16 = true;                     // eligible contractions on the f16 matrix pipe (conv3_h, conv_nin_h); option "split16" 0 = pure f32 kernels
-    size_t redo_off = 0, redo_ints = 0;      // redo flags of the split16 launches inside the arena (byte offset, count)
+    size_t redo_off = 0, redo_ints = 0;      // redo flags of a pass inside the arena (byte offset, count = 1 + images): [0] any, [1 + image]
+    bool p16 = true;                         // option "p16": tensors between split16 launches are kept pre-split (p16.hpp) where plan_p16 allows
+    bool p16_now = false;                    // the current carve holds them so (split16 on for both kernel families and p16)
+    bool any_p16 = false;                    // plan_p16 found at least one such tensor
+    int p16_max_res = 1;                     // largest resolution factor among them (bounds the pixels of a pass: kP16MaxPixels)
     bool dense_features = true;              // per-layer feature buffers + multi-source NIN GEMM instead of one concat tensor (densify_features)
     int concat_buf = -1;                     // build_graph: the skip-concat buffer, its slices (offset, logical width)
     std::vector<std::pair<int, int>> concat_slices;
@@ -198,8 +212,12 @@ struct dcscn_ctx {
     bool fold_force = false;                 // "fold_linear_tail" 2: fold even where the composite does more work than the layers
     bool fold_tail = true;                   // graph rewrite of the linear tail, see fold_linear_tail(); option "fold_linear_tail" 0 = layer by layer
     bool spatial_tiling = true;              // images larger than one pass are cut into haloed windows (run_tiled)
+    std::vector<unsigned long long> h_zrec;  // addresses of the zero records of the P16 planes in the current carve; device copy
+    unsigned long long* d_zrec = nullptr;
+    size_t zrec_cap = 0;
     std::vector<hipEvent_t> ev;              // event pool: 2 per launch
     size_t ev_used = 0;                      // events recorded since the last dcscn_get_profile
+    std::vector<int> ev_op;                  // launch index of each recorded pair (ops.size() = the float32 plan behind a pass)
     int ev_forwards = 0;                     // forwards recorded since the last dcscn_get_profile
     std::vector<double> prof_ms;
 };
@@ -234,6 +252,8 @@ bool stream_conv_supported(int in_quads, int out_tiles);
 void fuse_feat_stream(dcscn_ctx* h);
 void fuse_tail_stream(dcscn_ctx* h);
 void densify_features(dcscn_ctx* h);
+void plan_p16(dcscn_ctx* h);
+inline bool p16_active(const dcscn_ctx* h) { return h->p16 && h->any_p16 && h->split16 && h->split16_mask == 3; }
 // pack.hip
 int upload(dcscn_ctx* h, const void* host, size_t bytes, void** dev);
 int finalize_op(dcscn_ctx* h, Op& op);
@@ -241,7 +261,11 @@ int pack_feat_stream(dcscn_ctx* h, Op& op);
 int pack_tail_stream(dcscn_ctx* h, Op& op);
 // exec.hip
 int ensure_workspace(dcscn_ctx* h, int nb, int H, int W, hipStream_t stream);
-int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, const float* x2, float* y, hipStream_t stream);
+// redo = false: the launch of the pass (split16 kernels where the handle's options allow); true: the op's float32 launch gated by the
+// pass's redo flags -- only the images a split16 launch flagged are computed (exec.hip: run_forward)
+int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, const float* x2, float* y, hipStream_t stream, bool redo = false);
+bool op_on_split16(const dcscn_ctx* h, const Op& op);
+bool op_takes_h8(const dcscn_ctx* h, const Op& op);
 int halo_lr_pixels(const dcscn_ctx* h);
 int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, int H, int W, hipStream_t stream);
 int run_tiled(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, int H, int W, int64_t pass_pixels, hipStream_t stream);

@@ -179,14 +179,20 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * by a power of two per layer before the split; activations are split unscaled, so below |x| ~ 2^-3 their `lo` piece is an f16
  * subnormal and the pair carries an ABSOLUTE error floor of ~3e-8 per element instead of a relative 2^-22 -- immaterial for the
  * network's data (tested: inputs in [0, 1] as --max_value=1 feeds them meet the same 5e-6 bar on the bare branch,
- * test_small_magnitude_inputs_on_split16), but not "f32 accuracy for any input".  An activation beyond the f16 range
- * (|x| >= 65520) makes the affected outputs non-finite; the kernel flags their unit and the f32 kernel, launched behind it,
- * recomputes exactly the flagged units, so the result is safe for any finite f32 input.  Unit = a 16x16 pixel tile of one image
- * for the 3x3 / 5x5 kernels; a block of 256 consecutive pixels of the flat pixel list for the 1x1 GEMM -- such a block can straddle
- * two images (H * W not a multiple of 256), so an overflow in image A may send up to 255 pixels of image B to the f32 kernel:
- * B's values then differ from an all-split16 run at rounding level (both are within the parity bars), i.e. results are
- * independent of the rest of the batch per tile for 3x3 layers and up to that block granularity for 1x1 layers.
+ * test_small_magnitude_inputs_on_split16), but not "f32 accuracy for any input".  Per layer the split16 kernels are about twice
+ * as far from the float64 value as the f32 Winograd kernel (max error 2.9e-4 against 1.4e-4 on outputs of magnitude 260, rms 1.8e-5
+ * against 1.6e-5: profiles/r04_h16_conv3_harness.txt); end to end both families meet the same bars.  An activation beyond the f16
+ * range (|x| >= 65520) cannot be carried as a pair: the launch that meets it (a non-finite accumulator) or produces it (a P16 output,
+ * see "p16") raises the IMAGE's redo flag, and behind every pass the float32 launches of all layers run once more, gated by those
+ * flags: a flagged image is recomputed from the first layer on by the float32 kernels (bit-identical to a split16 = 0 run of
+ * that image), every other image of the batch keeps its split16 bits -- results never depend on what else is in the batch.  With no
+ * flag set (always, for image data) the gated launches exit at once.
  * 0 = the pure f32 kernels (conv_wino2 / conv_nin).
+ * "p16" (default 1; any time, the next forward re-carves the workspace): tensors that only split16 launches write and read (the
+ * feature maps, B1, Concat2) are kept PRE-SPLIT in the workspace -- per pixel and 32-channel chunk one aligned 128-byte record of
+ * f16 (hi | lo) units instead of float32 values, same 4 bytes per value (csrc/p16.hpp) -- so the split happens once, in the producer's
+ * epilogue, and the consumers stage their input tiles by LDS-DMA.  Same split, same products in the same order: results are
+ * bit-identical to p16 = 0.  Needs split16 = 1 (both kernel families); otherwise the float32 tensors of r04 are used.
  * "conv3_h8" (default 1; any time): 3x3 layers whose output channels form two channel groups (7 .. 12 tiles of 16) run on
  * conv3_h8 -- one persistent 8-wave workgroup per CU that stages a pixel tile's input once for both groups -- instead of two
  * conv3_h workgroups per tile; same filter image, bit-identical results.
@@ -279,6 +285,9 @@ int dcscn_debug_digests(dcscn_handle h, uint64_t* out, int capacity);
 
 /* Bytes of device workspace currently held. */
 int64_t dcscn_workspace_bytes(dcscn_handle h);
+/* How many workspace tensors the next forward keeps pre-split (option "p16"; 0 when the option, split16 or the graph rules it out).
+ * The reference has no counterpart (sess.run hides its buffers); diagnostic for tests and benchmarks.  After dcscn_finalize. */
+int dcscn_num_p16_tensors(dcscn_handle h);
 
 const char* dcscn_last_error(dcscn_handle h);
 int dcscn_destroy(dcscn_handle h);

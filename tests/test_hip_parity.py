@@ -767,3 +767,71 @@ def test_feat_stream_variants(oracle, variant):
     err = np.abs(y - ref).max() / scale_
     print(variant, kernels[:2], "max rel %.3g" % err)
     assert err <= 5e-6
+
+
+# ---- P16: pre-split tensors between split16 launches (csrc/p16.hpp, option "p16") ----------------------------------------------
+
+P16_CASES = [
+    ("L12_F196to48_x2", dict(), 2, 48, 48),
+    ("L12_F196to48_x2", dict(), 3, 37, 53),              # tiles that stick out of the image, on every layer
+    ("L8_F96to48_x2", dict(), 2, 40, 56),
+    ("L12_F196to48_x4", dict(), 1, 33, 47),
+    ("L7_F32to8_x2", dict(), 3, 31, 18),
+    ("wide-odd", dict(layers=3, filters=70, min_filters=45, nin_filters=40, nin_filters2=33), 2, 17, 33),   # Concat2 slice off a 16-channel boundary
+    ("odd-channels", dict(layers=4, filters=37, min_filters=13, nin_filters=21, nin_filters2=10), 2, 20, 50),
+    ("three-groups", dict(layers=3, filters=250, min_filters=120, nin_filters=64, nin_filters2=32), 1, 24, 40),
+]
+
+
+@pytest.mark.parametrize("case", P16_CASES, ids=[c[0] + "-%dx%dx%d" % c[2:] for c in P16_CASES])
+def test_p16_tensors_are_bit_identical_to_float32_tensors(oracle, case):
+    """Option p16 moves the f16 (hi, lo) split from every consumer's staging code into the producer's epilogue and changes the
+    workspace layout; the products and their order do not change -- every output bit must be the same, with the fold on and off,
+    and across sub-batching (a partial last pass uses planes carved for more images)."""
+    name, overrides, n, h, w = case
+    cfg = oracle.make_config(**(CONFIGS[name] if name in CONFIGS else overrides))
+    weights = oracle.synthetic_weights(cfg, seed=11)
+    x, x2 = synthetic_batch(n, h, w, cfg["scale"], seed=12)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    for fold in (True, False):
+        from dcscn_amd import engine
+        with engine.Engine(cfg, device=0) as eng:
+            eng.load_weights(weights, fold_tail=fold)
+            n16 = eng.num_p16_tensors()
+            y1 = eng.forward(x, x2)
+            eng.set_option("p16", 0)
+            assert eng.num_p16_tensors() == 0
+            y0 = eng.forward(x, x2)
+            eng.set_option("p16", 1)
+            eng.set_option("sub_batch_pixels", 2 * h * w)
+            y2 = eng.forward(x, x2)
+        print("%s fold=%s: %d P16 tensors, max-abs err %.3g" % (name, fold, n16, float(np.max(np.abs(y1 - ref)))))
+        if name.startswith("L12") or name.startswith("L8"):
+            assert n16 >= cfg["layers"], n16                  # every feature map at least
+        assert float(np.max(np.abs(y1 - ref))) <= MAX_ABS_TOL
+        assert np.array_equal(y1, y0), "p16 on / off differ in %d values" % int(np.sum(y1 != y0))
+        assert np.array_equal(y1, y2)
+
+
+def test_p16_overflow_recomputes_the_image_on_the_float32_plan(oracle):
+    """A flagged image (values beyond the f16 range) is recomputed from the first layer on by the float32 launches behind the pass --
+    bit-identical to a split16 = 0 run of it -- while the other image of the batch keeps the bits of a run without the huge one; the
+    next forward on the same handle (the float32 plan wrote float32 tensors over the P16 planes and their zero records) is clean."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS["L12_F196to48_x2"])
+    weights = oracle.synthetic_weights(cfg, seed=9)
+    x, x2 = synthetic_batch(3, 40, 33, 2, seed=10)
+    xb = x.copy()
+    xb[1] *= 4000.0
+    with engine.Engine(cfg, device=0) as eng:
+        eng.load_weights(weights)
+        assert eng.num_p16_tensors() > 0
+        clean = eng.forward(x, x2)
+        y = eng.forward(xb, x2)
+        again = eng.forward(x, x2)
+        eng.set_option("split16", 0)
+        y32 = eng.forward(xb, x2)
+    assert np.isfinite(y).all()
+    assert np.array_equal(y[0], clean[0]) and np.array_equal(y[2], clean[2])
+    assert np.array_equal(y[1], y32[1])
+    assert np.array_equal(again, clean)
