@@ -733,7 +733,7 @@ void plan_p16(dcscn_ctx* h) {
         return true;
     };
     auto can_write = [&](const Op& op, int k) {
-        if (op.kind == OP_CIN1) return k == 0 && op.out_off[0] == 0;
+        if (op.kind == OP_CIN1) return k == 0 && op.out_off[0] == 0 && op.ks <= 3;   // (conv_cin1's octet-per-thread store path holds 2 x taps filter quads)
         if (op.kind != OP_CONV || !op.h16.on || op.fold_s > 0 || op.ps != 1 || op.residual || op.dwk != 0) return false;
         if (op.out_off[k] % 16 != 0) return false;
         return k == 0 || op.split % 16 == 0;

@@ -90,10 +90,57 @@ __global__ __launch_bounds__(256) void conv_cin1(const Cin1Args a, int tpp_log2)
     const int cl = tid & (tpp - 1);
     const int pl = tid >> tpp_log2;
     const int ppi = 256 >> tpp_log2;   // pixels per iteration
-    const bool o16 = a.out.p16.base != nullptr;   // P16 destination (p16.hpp): the (hi, lo) halves of the quad, 8 bytes each
-    const float m1 = opaque_minus_one();
-    const h2 zero2 = p16_opaque_zero2();
+    const bool o16 = a.out.p16.base != nullptr;   // P16 destination (p16.hpp)
     float chk = 0.0f;
+    if (o16) {
+        // a thread owns a channel OCTET of a pixel: its (hi | lo) units are one 32-byte store, four adjacent lanes fill a 128-byte record.
+        // tpp16 threads per pixel (a power of two >= octets), the rest of the geometry as below
+        const int octs = a.out.p16.octs;
+        int t16 = 0;
+        while ((1 << t16) < octs && t16 < 6) ++t16;
+        const int tpp16 = 1 << t16, cl8 = tid & (tpp16 - 1), pl8 = tid >> t16, ppi8 = 256 >> t16;
+        const float m1 = opaque_minus_one();
+        const h2 zero2 = p16_opaque_zero2();
+        for (int c8 = cl8; c8 < octs; c8 += tpp16) {
+            const bool two = 2 * c8 + 1 < c4n;         // the last octet of an odd quad count: its upper half is written as zeros
+            f32x4 wr[TAPS][2];
+            const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                wr[t][0] = *reinterpret_cast<const f32x4*>(ws + t * cs + 8 * c8);
+                wr[t][1] = two ? *reinterpret_cast<const f32x4*>(ws + t * cs + 8 * c8 + 4) : z4;
+            }
+            const f32x4 bv0 = *reinterpret_cast<const f32x4*>(bs + 8 * c8), bv1 = two ? *reinterpret_cast<const f32x4*>(bs + 8 * c8 + 4) : z4;
+            const f32x4 av0 = *reinterpret_cast<const f32x4*>(as + 8 * c8), av1 = two ? *reinterpret_cast<const f32x4*>(as + 8 * c8 + 4) : z4;
+            const int chunk = c8 >> 2, rem = octs - 4 * chunk;
+            const int rec = rem >= 4 ? 128 : 32 * rem;
+            char* plane = a.out.p16.base + (long long)chunk * a.out.p16.plane + 128 + (c8 & 3) * 32;
+            for (int p = pl8; p < T * T; p += ppi8) {
+                const int py = p >> 4, px = p & 15;
+                const int gy = y0 + py, gx = x0 + px;
+                if (gy >= a.H || gx >= a.W) continue;
+                f32x4 s0 = z4, s1 = z4;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const float xv = xs[(py + t / KS) * HT + px + t % KS];
+                    s0 += wr[t][0] * xv;
+                    s1 += wr[t][1] * xv;
+                }
+                f32x4 v0 = bv0, v1 = bv1;
+                v0 += s0; v1 += s1;                    // (the float32 path's association: bias + (sum over taps))
+                v0.x = activate1(v0.x, av0.x, a.act); v0.y = activate1(v0.y, av0.y, a.act); v0.z = activate1(v0.z, av0.z, a.act); v0.w = activate1(v0.w, av0.w, a.act);
+                if (two) { v1.x = activate1(v1.x, av1.x, a.act); v1.y = activate1(v1.y, av1.y, a.act); v1.z = activate1(v1.z, av1.z, a.act); v1.w = activate1(v1.w, av1.w, a.act); }
+                else v1 = z4;
+                h8 hi, lo;
+                split8(v0, v1, m1, hi, lo);
+                const u32x4 hu = __builtin_bit_cast(u32x4, hi);
+                chk = p16_check(p16_check(p16_check(p16_check(chk, hu.x, zero2), hu.y, zero2), hu.z, zero2), hu.w, zero2);
+                const size_t pix = ((size_t)img * a.H + gy) * a.W + gx;
+                *reinterpret_cast<h8*>(plane + pix * rec) = hi;
+                *reinterpret_cast<h8*>(plane + pix * rec + 16) = lo;
+            }
+        }
+    } else
     for (int c4 = cl; c4 < c4n; c4 += tpp) {
         f32x4 wr[TAPS];
 #pragma unroll
@@ -117,32 +164,7 @@ __global__ __launch_bounds__(256) void conv_cin1(const Cin1Args a, int tpp_log2)
             v.z = activate1(v.z, av.z, a.act);
             v.w = activate1(v.w, av.w, a.act);
             const size_t pix = ((size_t)img * a.H + gy) * a.W + gx;
-            if (o16) {
-                const int oct = c4 >> 1, chunk = oct >> 2, rem = a.out.p16.octs - 4 * chunk;
-                const int rec = rem >= 4 ? 128 : 32 * rem;
-                h4 hi, lo;
-                split4(v, m1, hi, lo);
-                const u32x2 hu = __builtin_bit_cast(u32x2, hi), lu = __builtin_bit_cast(u32x2, lo);
-                chk = p16_check(p16_check(chk, hu.x, zero2), hu.y, zero2);
-                char* dst = a.out.p16.base + (long long)chunk * a.out.p16.plane + 128 + pix * rec + (oct & 3) * 32 + (c4 & 1) * 8;
-                *reinterpret_cast<u32x2*>(dst) = hu;
-                *reinterpret_cast<u32x2*>(dst + 16) = lu;
-            } else
             *reinterpret_cast<f32x4*>(a.out.ptr + pix * a.out.stride + a.out.off + 4 * c4) = v;
-        }
-        // a P16 tensor holds whole octets: an odd quad count leaves the upper half of the last octet to be written as zeros
-        if (o16 && c4 == c4n - 1 && (c4n & 1)) {
-            for (int p = pl; p < T * T; p += ppi) {
-                const int py = p >> 4, px = p & 15;
-                const int gy = y0 + py, gx = x0 + px;
-                if (gy >= a.H || gx >= a.W) continue;
-                const size_t pix = ((size_t)img * a.H + gy) * a.W + gx;
-                const int oct = c4 >> 1, chunk = oct >> 2, rem = a.out.p16.octs - 4 * chunk;
-                const int rec = rem >= 4 ? 128 : 32 * rem;
-                char* dst = a.out.p16.base + (long long)chunk * a.out.p16.plane + 128 + pix * rec + (oct & 3) * 32 + 8;
-                *reinterpret_cast<u32x2*>(dst) = u32x2{0u, 0u};
-                *reinterpret_cast<u32x2*>(dst + 16) = u32x2{0u, 0u};
-            }
         }
     }
     if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + img] = 1; }     // an output beyond the f16 range: the image goes to the float32 plan
