@@ -108,19 +108,6 @@ int dcscn_create(const dcscn_config* cfg, int device, dcscn_handle* out) {
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
                 h->workspace_budget = std::min<int64_t>(h->workspace_budget, std::max<int64_t>((int64_t)(free_b / 10 * 6), (int64_t)256 << 20));
         }
-        if (getenv("DCSCN_CU_SPLIT") && atoi(getenv("DCSCN_CU_SPLIT")) > 0 && atoi(getenv("DCSCN_CU_SPLIT")) < h->n_cus) {
-            // experiment (plan.h: cu_split): bit i of the mask is compute unit i, dealt round-robin over the XCDs -- the lowest k bits are
-            // k / 8 units of every XCD
-            h->cu_split = atoi(getenv("DCSCN_CU_SPLIT"));
-            const int words = (h->n_cus + 31) / 32;
-            std::vector<uint32_t> big(words, 0), small(words, 0);
-            for (int i = 0; i < h->n_cus; ++i) (i < h->cu_split ? small : big)[i / 32] |= 1u << (i % 32);
-            if ((e = hipExtStreamCreateWithCUMask(&h->s_big, (uint32_t)words, big.data())) != hipSuccess ||
-                (e = hipExtStreamCreateWithCUMask(&h->s_small, (uint32_t)words, small.data())) != hipSuccess) {
-                rc = fail(h, DCSCN_ERR_HIP, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
-                break;
-            }
-        }
         rc = build_graph(h);
     } while (0);
     if (rc != DCSCN_OK) {

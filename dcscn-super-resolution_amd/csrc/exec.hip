@@ -275,7 +275,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
             b.bias = op.h16.d_bias;
             b.tail_octs = op.h16.tail_octs;
             b.alpha = op.h16.d_alpha;
-            if (op_takes_h8(h, op)) HIP_TRY(h, c3e_launch(op.h16.nt, b, op.h16.n_tiles, h->n_cus - h->cu_split, stream));
+            if (op_takes_h8(h, op)) HIP_TRY(h, c3e_launch(op.h16.nt, b, op.h16.n_tiles, h->n_cus, stream));
             else HIP_TRY(h, c3h_launch(op.h16.nt, b, op.h16.n_tiles, stream));
         }
         return DCSCN_OK;
@@ -520,28 +520,6 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         if (!h->d_digest) HIP_TRY(h, hipMalloc((void**)&h->d_digest, 1024 * sizeof(unsigned long long)));
         HIP_TRY(h, hipMemsetAsync(h->d_digest, 0, 1024 * sizeof(unsigned long long), stream));
     }
-    // (experiment, plan.h: cu_split) which stream a launch goes to, and the event hop between streams
-    hipStream_t cur_stream = stream;
-    h->hop_used = 0;
-    auto hop = [&](hipStream_t to) -> hipError_t {
-        if (to == cur_stream) return hipSuccess;
-        if (h->hop_used == h->hop_ev.size()) {
-            hipEvent_t e;
-            hipError_t ce = hipEventCreateWithFlags(&e, hipEventDisableTiming);
-            if (ce != hipSuccess) return ce;
-            h->hop_ev.push_back(e);
-        }
-        hipEvent_t e = h->hop_ev[h->hop_used++];
-        hipError_t ce = hipEventRecord(e, cur_stream);
-        if (ce == hipSuccess) ce = hipStreamWaitEvent(to, e, 0);
-        cur_stream = to;
-        return ce;
-    };
-    auto op_stream = [&](const Op& op) -> hipStream_t {
-        if (h->cu_split <= 0 || !h->s_big) return stream;
-        const bool hbm = op.kind == OP_CIN1 || op.kind == OP_COUT1 || (op.kind == OP_CONV && (op.shape.nin || op.fold_s > 0));
-        return hbm ? h->s_small : h->s_big;
-    };
     for (int b = 0; b < batches; ++b) {
         const int b0 = b * nb;
         const int cnt = std::min(nb, n - b0);
@@ -562,8 +540,7 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
             size_t evi = 0;
             if (h->profile) { evi = ev_pair(i); HIP_TRY(h, hipEventRecord(h->ev[evi], stream)); }
             if (h->debug_poison) HIP_TRY(h, debug_poison_launch(h->debug_poison, stream));
-            HIP_TRY(h, hop(op_stream(h->ops[i])));
-            rc = launch_op(h, h->ops[i], cnt, H, W, xb, x2b, yb, cur_stream);
+            rc = launch_op(h, h->ops[i], cnt, H, W, xb, x2b, yb, stream);
             if (rc) {
                 abandon_capture();
                 return rc;
@@ -585,7 +562,6 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         }
         // the float32 plan: every launch again on its float32 kernel, gated by the pass's redo flags -- computes the images a split16 launch
         // flagged (a value beyond the f16 range) from the first layer on, as float32 tensors in the same workspace; exits at once otherwise
-        HIP_TRY(h, hop(stream));
         if (any_h16) {
             size_t evi = 0;
             if (h->profile) { evi = ev_pair(nops); HIP_TRY(h, hipEventRecord(h->ev[evi], stream)); }

@@ -200,13 +200,6 @@ struct dcscn_ctx {
     int split16_mask = 3;                    // debugging aid (option "split16" 2 / 3): bit 0 = conv3_h, bit 1 = conv_nin_h
     bool split16 = true;                     // eligible contractions on the f16 matrix pipe (conv3_h, conv_nin_h); option "split16" 0 = pure f32 kernels
     size_t redo_off = 0, redo_ints = 0;      // redo flags of a pass inside the arena (byte offset, count = 1 + images): [0] any, [1 + image]
-    // experiment (env DCSCN_CU_SPLIT = k, tools/overlap_probe.py): the HBM-bound launches of a pass (first layer, wide 1x1 GEMM, folded tail)
-    // go to a stream masked to k compute units, the 3x3 stack to one masked to the others -- two handles working on two half batches
-    // then overlap one's HBM-bound launches with the other's matrix-bound ones
-    int cu_split = 0;
-    hipStream_t s_big = nullptr, s_small = nullptr;
-    std::vector<hipEvent_t> hop_ev;
-    size_t hop_used = 0;
     bool p16 = true;                         // option "p16": tensors between split16 launches are kept pre-split (p16.hpp) where plan_p16 allows
     bool p16_now = false;                    // the current carve holds them so (split16 on for both kernel families and p16)
     bool any_p16 = false;                    // plan_p16 found at least one such tensor

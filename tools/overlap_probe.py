@@ -1,7 +1,7 @@
 """can the HBM-bound launches of the L12 pass (first layer, wide 1x1 GEMM, folded tail: ~3.9 of ~19.4 ms, matrix pipe
 idle) run in the shadow of the matrix-bound 3x3 stack of ANOTHER half batch?
 
-  DCSCN_CU_SPLIT=k  (library experiment, csrc/plan.h: cu_split): the HBM-bound launches of a handle go to a stream masked to k compute
+  DCSCN_CU_SPLIT=k  (library hook of the experiment commit, since removed): the HBM-bound launches of a handle go to a stream masked to k compute
   units (k / 8 per XCD), the 3x3 launches to a stream masked to the other 256 - k (conv3_h8's persistent grid shrinks to match).
 Two handles, 512 patches each, enqueued alternately; reference = one handle, 1024 patches, one stream, no masks.
 
