@@ -42,6 +42,15 @@ __device__ __forceinline__ void glds16v(const void* gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// the same with the non-temporal policy: data that ONE workgroup reads ONCE (MI355X_MICROARCH.md "nt-weights": issued -> landed -18 %)
+__device__ __forceinline__ void glds16v_nt(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 template <int NT>
 struct NinGeom {
     static constexpr int THREADS = 256;

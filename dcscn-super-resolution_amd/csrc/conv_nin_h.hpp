@@ -17,6 +17,10 @@
 #include "split16.hpp"
 #include "p16.hpp"
 
+#ifndef NINH_A_NT
+#define NINH_A_NT 0        // 1: input pieces with the non-temporal policy -- measured r05: 2.91 -> 4.18 ms (the producers' lines are still on their way through L2 / MALL)
+#endif
+
 namespace dcscn {
 
 template <int NT, int S = 2>
@@ -90,7 +94,8 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
         constexpr int r = decltype(r_)::value;
         if constexpr (MULTI) {
             const char* src = reinterpret_cast<const char*>(((unsigned long long)ent.y << 32) | ent.x) + (unsigned long long)a_pix[r] * ent.z + (IN16 ? (dq & 1) * 16 : 0);
-            glds16v(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
+            if constexpr (NINH_A_NT) glds16v_nt(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
+            else glds16v(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
         } else {
             const int c0 = chunk * G::KC + 4 * dq;
             glds16(a_base, a_off[r] + (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4), lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);

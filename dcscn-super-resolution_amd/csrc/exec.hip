@@ -74,6 +74,7 @@ static P16Desc p16_desc(const dcscn_ctx* h, int id) {
 }
 
 bool op_on_split16(const dcscn_ctx* h, const Op& op) {
+    if (op.kind == OP_STREAM || op.kind == OP_TAIL) return h->split16 && op.h16.on && (h->split16_mask & 1);      // the F16 instantiation of the streamed kernels
     return op.kind == OP_CONV && h->split16 && op.h16.on && (h->split16_mask & (op.shape.nin ? 2 : 1));
 }
 
@@ -98,14 +99,15 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
               hipStream_t stream, bool redo) {
     const int Hr = H * op.res, Wr = W * op.res;
     int32_t* const redo_flags = reinterpret_cast<int32_t*>(static_cast<char*>(h->arena) + h->redo_off);
-    if (redo && (op.kind == OP_TAIL || op.kind == OP_STREAM)) return fail(h, DCSCN_ERR_STATE, "float32 plan over a streamed launch");
+    const bool stream16 = !redo && op_on_split16(h, op);          // streamed kernels: the F16 instantiation on its own filter image
     if (op.kind == OP_TAIL) {
         TailArgs a = op.tail;
         a.c2 = buf_ptr(h, op.in_buf);
         a.c2_stride = h->bufs[op.in_buf].stride;
         a.x2 = x2;
         a.y = y;
-        a.blob = op.d_w;
+        a.blob = stream16 ? static_cast<const float*>(op.h16.d_w) : op.d_w;
+        a.redo = redo_flags; a.redo_check = redo ? 1 : 0;
         a.N = nb; a.H = H; a.W = W;
         a.halo = 2;
         if (W <= kStreamPX) { a.n_strips = 1; a.useful_w = W; }
@@ -118,7 +120,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.n_jobs = (int)(cols * a.n_blocks);
         a.jobs_per_wg = (a.n_jobs + 255) / 256;
         const int grid = (a.n_jobs + a.jobs_per_wg - 1) / a.jobs_per_wg;
-        HIP_TRY(h, tail_launch(a, grid, stream));
+        HIP_TRY(h, tail_launch(a, grid, stream16, stream));
         return DCSCN_OK;
     }
     if (op.kind == OP_STREAM) {
@@ -126,7 +128,8 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.x = x;
         a.out = buf_ptr(h, op.out_buf[0]);
         a.out_stride = h->bufs[op.out_buf[0]].stride;
-        a.blob = op.d_w;
+        a.blob = stream16 ? static_cast<const float*>(op.h16.d_w) : op.d_w;
+        a.redo = redo_flags; a.redo_check = redo ? 1 : 0;
         a.N = nb; a.H = H; a.W = W;
         a.halo = a.L + 1;
         // column strips of 48 computed pixels; row blocks only where whole images do not fill the chip
@@ -148,7 +151,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
             a.dbg = dbg;
         }
 #endif
-        HIP_TRY(h, stream_launch(a, grid, stream));
+        HIP_TRY(h, stream_launch(a, grid, stream16, stream));
 #ifdef STREAM_DBG
         if (a.dbg) {
             std::vector<long long> host(16 * 64 * 4);

@@ -42,9 +42,7 @@
                           // 16 = PROJECTION of a split16 variant: per two 16-channel chunks the 8 NT v_mfma_f32_16x16x4_f32 are replaced by the hi / lo
                           // split of the B values (12 VALU per pixel tile) and 3 NT v_mfma_f32_16x16x32_f16 on stand-in A operands (finite bit patterns)
 #endif
-#if STREAM_ABL == 16
 #include "split16.hpp"
-#endif
 
 namespace dcscn {
 
@@ -123,6 +121,13 @@ __device__ __forceinline__ f32x4 stream_prelu(f32x4 v, f32x4 am1) {
 }
 
 constexpr f32x4 kStreamZero = {0.0f, 0.0f, 0.0f, 0.0f};
+
+// A value stored to global memory by an F16 kernel is not finite (an activation beyond the f16 range somewhere upstream of it): the image
+// goes to the float32 plan (exec.hip: run_forward).  `z` = opaque_zero().
+__device__ __forceinline__ void stream_flag(int32_t* redo, int img, const f32x4 v, float z) {
+    const float c = nonfinite_acc(0.0f, v, z);
+    if (c != c && redo) { redo[0] = 1; redo[1 + img] = 1; }
+}
 
 // ---- CNN1: Y -> depthwise 3x3 (one channel) -> pointwise 1 -> C1, bias, PReLU ------------------------------------
 __device__ __forceinline__ void stream_first_role(const StreamArgs& a, unsigned lds0, int j0, int rows, int T, int lane) {
@@ -222,11 +227,22 @@ template <int QL> struct StreamChunk {
 // (compile time: every LDS offset below is an immediate).
 // `init[n]` (the bias) is the C operand of each accumulator's FIRST MFMA: no zero fill, no bias add afterwards -- on this
 // chip every VALU instruction costs matrix-pipe time too (tools/mfma_valu_overlap.hip: they do not overlap).
-template <int QUADS, int NT, int MT = kStreamMT>
+//
+// F16 (r05): the pointwise GEMM on v_mfma_f32_16x16x32_f16 at f32 accuracy (split16.hpp): the depthwise
+// outputs of TWO 16-channel chunks are one K = 32 B operand (lane q: the 4 channels of quad q of each chunk), split into f16 (hi, lo) in
+// registers; the filters are f16 (hi, lo) fragments scaled by 2^e (pack.hip: stream_f16_image), three products per accumulator -- 3 NT MT
+// instructions of 16 cycles per chunk pair instead of 8 NT MT of 32, and beside the f16 instruction the depthwise VALU work of the SIMD's
+// other waves overlaps (profiles/r03_pipe_probe.txt).  An odd last chunk takes the K = 16 form.  `init` holds the bias times 2^e; the
+// caller multiplies the accumulators by 2^-e.  Every chunk is treated as four quads: lanes of a missing quad read a valid one (K::quad) and
+// meet zero filter rows.
+// F16: `init` is not read -- the bias (times 2^e) is fetched from LDS at the first MFMA (init_addr = address of tile 0's float4 of this
+// lane, tile n 64 bytes further): eight registers fewer across the depthwise part.
+template <int QUADS, int NT, int MT = kStreamMT, bool F16 = false>
 __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], const f32x4 (&init)[NT], unsigned lds0, const unsigned (&rowb)[3], int dww, int wpo,
-                                             int q, int lane) {
+                                             int q, int lane, unsigned init_addr = 0) {
     constexpr int CH = (QUADS + 3) / 4;
     constexpr unsigned PX = (unsigned)(QUADS | 1) * 16u;
+    f32x4 dpair[F16 ? MT : 1];                                // F16: the first chunk of a pair waits here for the second
 #if STREAM_ABL == 16
     f32x4 dkeep[MT];
 #endif
@@ -235,9 +251,11 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], const f32x4 (
         constexpr int QL = ch == CH - 1 ? QUADS - 4 * (CH - 1) : 4;
         using K = StreamChunk<QL>;
         const unsigned qoff = (unsigned)(ch * 4 + K::quad(q)) * 16u;
-        f32x4 wp[NT];
+        f32x4 wp[F16 ? 1 : NT];
+        if constexpr (!F16) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) wp[n] = stream_ld(lds0 + wpo + (unsigned)((ch * NT + n) * 64 + lane) * 16u);
+            for (int n = 0; n < NT; ++n) wp[n] = stream_ld(lds0 + wpo + (unsigned)((ch * NT + n) * 64 + lane) * 16u);
+        }
         f32x4 d[MT];
         const unsigned dwb = lds0 + dww + qoff;
         // rows are double buffered: the reads of row dy + 1 are in flight while row dy is multiplied (the compiler
@@ -267,12 +285,23 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], const f32x4 (
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
+        if constexpr (F16 && MT > 1) {
+            // single-buffered rows: 32 registers fewer than the prefetch of row dy + 1 (this kernel sits at 128); beside f16 MFMAs the SIMD's
+            // other waves fill the LDS latency
+            fetch(I0{}, I0{});
+            mult(I0{}, std::true_type{});
+            fetch(I1{}, I0{});
+            mult(I0{}, std::false_type{});
+            fetch(I2{}, I0{});
+            mult(I0{}, std::false_type{});
+        } else {
         fetch(I0{}, I0{});
         fetch(I1{}, I1{});
         mult(I0{}, std::true_type{});
         fetch(I2{}, I0{});
         mult(I1{}, std::false_type{});
         mult(I0{}, std::false_type{});
+        }
         if (QL < 3) {
             // keep the packed depthwise: without this the compiler sinks pick()'s lane-dependent selects into the 9 x (MT + 2)
             // window values and runs the taps unpacked
@@ -280,6 +309,46 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], const f32x4 (
             for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(d[m]));
         }
         // (lanes of a missing quad hold the depthwise of a real one: finite, times zero filter rows)
+        if constexpr (F16) {
+            const float m1 = opaque_minus_one();
+            if constexpr ((ch & 1) == 0 && ch != CH - 1) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) dpair[m] = d[m];
+            } else if constexpr ((ch & 1) == 1) {
+                constexpr bool first = ch == 1;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    h8 bh, bl;
+                    split8(dpair[m], d[m], m1, bh, bl);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const h8 ah = __builtin_bit_cast(h8, stream_ld(lds0 + wpo + (unsigned)(((ch - 1) * NT + 2 * n) * 64 + lane) * 16u));
+                        const h8 al = __builtin_bit_cast(h8, stream_ld(lds0 + wpo + (unsigned)(((ch - 1) * NT + 2 * n + 1) * 64 + lane) * 16u));
+                        f32x4 c0 = first ? stream_ld(init_addr + (unsigned)n * 64u) : acc[m][n];
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c0, 0, 0, 0);
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c0, 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c0, 0, 0, 0);
+                    }
+                }
+            } else {                                          // an odd last chunk: K = 16, the lane's slot holds [hi 0-3 | lo 0-3]
+                constexpr bool first = ch == 0;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    h4 bh, bl;
+                    split4(d[m], m1, bh, bl);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const f32x4 wv = stream_ld(lds0 + wpo + (unsigned)((ch * NT + n) * 64 + lane) * 16u);
+                        const u32x4 wu = __builtin_bit_cast(u32x4, wv);
+                        const h4 ah = __builtin_bit_cast(h4, u32x2{wu.x, wu.y}), al = __builtin_bit_cast(h4, u32x2{wu.z, wu.w});
+                        f32x4 c0 = first ? stream_ld(init_addr + (unsigned)n * 64u) : acc[m][n];
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c0, 0, 0, 0);
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c0, 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c0, 0, 0, 0);
+                    }
+                }
+            }
+        } else {
 #if STREAM_ABL == 16
         if constexpr ((ch & 1) == 0 && ch != CH - 1) {
 #pragma unroll
@@ -314,14 +383,16 @@ __device__ __forceinline__ void stream_dw_pw(f32x4 (&acc)[MT][NT], const f32x4 (
                 }
             }
 #endif
+        }
     });
 }
 
 // ---- CNN2 .. CNNL, B2: depthwise 3x3 from the predecessor's ring -> pointwise GEMM -> bias, PReLU -----------------
 // QUADS = channel quads of the input, NT = 16-channel tiles of the output (compile time: no branches between the MFMAs)
-template <int QUADS, int NT>
+template <int QUADS, int NT, bool F16, bool GATE>
 __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const StreamConv& c, unsigned lds0, int j0, int rows, int T, int lane) {
     const int j = lane & 15, q = lane >> 4;
+    const float zflag = opaque_zero();
     constexpr unsigned in_px = (unsigned)(QUADS | 1) * 16u, in_row = (unsigned)kStreamRowPx * in_px;
     StreamCursor cur;
     for (int t = 0; t < T; ++t) {
@@ -338,14 +409,16 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + c.in.off + (unsigned)((g + 2 * c.in.slots - 1 + dy) % c.in.slots) * in_row + (unsigned)(3 * j) * in_px;   // rows g-1, g, g+1
                 f32x4 bs[NT];
+                if constexpr (!F16) {
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bs[n] = stream_ld(lds0 + c.ba + (unsigned)(n * 4 + q) * 16u);
-                stream_dw_pw<QUADS, NT>(acc, bs, lds0, rowb, c.dww, c.wp, q, lane);
+                    for (int n = 0; n < NT; ++n) bs[n] = stream_ld(lds0 + c.ba + (unsigned)(n * 4 + q) * 16u);
+                }
+                stream_dw_pw<QUADS, NT, kStreamMT, F16>(acc, bs, lds0, rowb, c.dww, c.wp, q, lane, lds0 + c.ba + (unsigned)q * 16u);
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const f32x4 al = stream_ld(lds0 + c.ba + 128u + (unsigned)(n * 4 + q) * 16u);
 #pragma unroll
-                    for (int m = 0; m < kStreamMT; ++m) acc[m][n] = stream_prelu(acc[m][n], al);
+                    for (int m = 0; m < kStreamMT; ++m) acc[m][n] = stream_prelu(F16 ? acc[m][n] * c.inv : acc[m][n], al);
                 }
                 if (ri.sx < 0 || ri.sx + kStreamPX > a.W) {          // the strip sticks out of the image: SAME padding is zero
 #pragma unroll
@@ -357,14 +430,16 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
                         }
                     }
                 }
-                if (c.to_global && ri.store) {
+                if (c.to_global && ri.store && (!GATE || a.redo[1 + ri.img] != 0)) {     // (GATE = the float32 plan: flagged images only)
 #pragma unroll
                     for (int m = 0; m < kStreamMT; ++m) {
                         const int cx = ri.sx + 3 * j + m;
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
-                            if (cx >= ri.ux0 && cx < ri.ux1 && n * 4 + q < c.out.quads)
+                            if (cx >= ri.ux0 && cx < ri.ux1 && n * 4 + q < c.out.quads) {
+                                if (F16) stream_flag(a.redo, ri.img, acc[m][n], zflag);
                                 *reinterpret_cast<f32x4*>(a.out + (((size_t)ri.img * a.H + ri.r) * a.W + cx) * a.out_stride + (n * 4 + q) * 4) = acc[m][n];
+                            }
                     }
                 }
             }
@@ -389,8 +464,10 @@ __device__ __forceinline__ void stream_conv_role(const StreamArgs& a, const Stre
 }
 
 // ---- A1 || B1: one (feature layer, row) contribution per step and wave --------------------------------------------
+template <bool F16, bool GATE>
 __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsigned lds0, int j0, int rows, int T, int) {
     const int L = a.L;
+    const float zflag = opaque_zero();
     f32x4 acc[2][kStreamMT][2];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -426,6 +503,53 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
 #pragma unroll
                     for (int m = 0; m < kStreamMT; ++m) xkeep[m] = f32x4{1.0f, 2.0f, 3.0f, 4.0f};
 #endif
+                    if constexpr (F16) {
+                        // chunk pairs on v_mfma_f32_16x16x32_f16, an odd last chunk on the K = 16 form (stream_dw_pw, F16); a short last
+                        // chunk's missing quads read a valid one against zero filter rows
+                        const float m1 = opaque_minus_one();
+                        const int lql = s.last_ql;
+                        const int lcq = lql >= 3 ? min(q, lql - 1) : lql == 2 ? (q & 1) : 0;
+#pragma unroll 1
+                        for (int cp = 0; 2 * cp + 1 < s.chunks; ++cp) {
+                            const unsigned q0 = (unsigned)(8 * cp + q) * 16u, q1 = (unsigned)(8 * cp + 4 + (2 * cp + 1 == s.chunks - 1 ? lcq : q)) * 16u;
+                            const unsigned wb = lds0 + s.w + (unsigned)(cp * 4 * 64 + lane) * 16u;
+#pragma unroll
+                            for (int m = 0; m < kStreamMT; ++m) {
+                                const f32x4 x0 = stream_ld(rowb + (unsigned)(m * s.ring.units) * 16u + q0), x1 = stream_ld(rowb + (unsigned)(m * s.ring.units) * 16u + q1);
+                                h8 bh, bl;
+                                split8(x0, x1, m1, bh, bl);
+                                // (the fragments of one tile at a time, re-read per pixel tile: LDS reads are free beside f16 MFMAs, registers are not)
+#pragma unroll
+                                for (int n = 0; n < 2; ++n) {
+                                    const h8 ah = __builtin_bit_cast(h8, stream_ld(wb + (unsigned)n * 2048u)), al = __builtin_bit_cast(h8, stream_ld(wb + (unsigned)n * 2048u + 1024u));
+                                    acc[p][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[p][m][n], 0, 0, 0);
+                                    acc[p][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[p][m][n], 0, 0, 0);
+                                    acc[p][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[p][m][n], 0, 0, 0);
+                                    asm volatile("" ::: "memory");
+                                }
+                            }
+                        }
+                        if (s.chunks & 1) {
+                            const int ch = s.chunks - 1;
+                            const unsigned qo = (unsigned)(4 * ch + lcq) * 16u;
+                            const u32x4 w0 = __builtin_bit_cast(u32x4, stream_ld(lds0 + s.w + (unsigned)((ch * 2 + 0) * 64 + lane) * 16u));
+                            const u32x4 w1 = __builtin_bit_cast(u32x4, stream_ld(lds0 + s.w + (unsigned)((ch * 2 + 1) * 64 + lane) * 16u));
+                            const h4 a0h = __builtin_bit_cast(h4, u32x2{w0.x, w0.y}), a0l = __builtin_bit_cast(h4, u32x2{w0.z, w0.w});
+                            const h4 a1h = __builtin_bit_cast(h4, u32x2{w1.x, w1.y}), a1l = __builtin_bit_cast(h4, u32x2{w1.z, w1.w});
+#pragma unroll
+                            for (int m = 0; m < kStreamMT; ++m) {
+                                h4 bh, bl;
+                                split4(stream_ld(rowb + (unsigned)(m * s.ring.units) * 16u + qo), m1, bh, bl);
+                                f32x4 c0 = acc[p][m][0], c1 = acc[p][m][1];
+                                c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a0l, bh, c0, 0, 0, 0);
+                                c1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a1l, bh, c1, 0, 0, 0);
+                                c0 = __builtin_amdgcn_mfma_f32_16x16x16f16(a0h, bl, c0, 0, 0, 0);
+                                c1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a1h, bl, c1, 0, 0, 0);
+                                acc[p][m][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0h, bh, c0, 0, 0, 0);
+                                acc[p][m][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1h, bh, c1, 0, 0, 0);
+                            }
+                        }
+                    } else
 #pragma unroll 1
                     for (int ch = 0; ch < s.chunks; ++ch) {
                         // StreamChunk<ql> with a run-time ql (one code path: this role is short of registers, not of VALU slots)
@@ -488,6 +612,7 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
                     }
                 }
                 if (last) {
+                    const bool gate = ri.store && (!GATE || a.redo[1 + ri.img] != 0);     // (GATE = the float32 plan: flagged images only)
                     // bias, PReLU; A1 -> Concat2 (global), the B1 quads (tile 0, nb <= 16) -> the B1 ring, which has a FOURTH slot so
                     // that the row can be written while B2 reads the three before it (no registers held across the barrier)
 #pragma unroll
@@ -499,13 +624,15 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
                         for (int m = 0; m < kStreamMT; ++m) {
                             const int cx = ri.sx + 3 * j + m;
                             const bool ok = !ri.zero && cx >= 0 && cx < a.W;
-                            const f32x4 r = stream_prelu(acc[p][m][n] + bs, al);
+                            const f32x4 r = stream_prelu(F16 ? acc[p][m][n] * a.nin_inv + bs : acc[p][m][n] + bs, al);
                             const f32x4 v = ok ? r : kStreamZero;
                             acc[p][m][n] = kStreamZero;
                             if (n == 0 && q < a.nb_quads)
                                 stream_st(lds0 + a.b1.off + (((unsigned)(g & 3) * kStreamRowPx + 3 * j + m + 1) * a.b1.units + q) * 16u, v);
-                            if (ri.store && cx >= ri.ux0 && cx < ri.ux1 && quad >= a.nb_quads && quad * 4 < a.out_stride)
+                            if (gate && cx >= ri.ux0 && cx < ri.ux1 && quad >= a.nb_quads && quad * 4 < a.out_stride) {
+                                if (F16) stream_flag(a.redo, ri.img, v, zflag);
                                 *reinterpret_cast<f32x4*>(a.out + (((size_t)ri.img * a.H + ri.r) * a.W + cx) * a.out_stride + quad * 4) = v;
+                            }
                         }
                     }
                 }
@@ -526,8 +653,13 @@ __device__ __forceinline__ void stream_nin_role(const StreamArgs& a, int w, unsi
     }
 }
 
+// F16 = the pointwise GEMMs and A1 || B1 on the f16 matrix pipe (stream_dw_pw); false = v_mfma_f32_16x16x4_f32 (split16 = 0).
+// GATE = the float32 plan of flagged images (F16 = false): leaves at once unless the pass flagged an image, stores only flagged images --
+// its own instantiation, so that the kernels of every pass carry none of it (they sit at their 128-register cap)
+template <bool F16, bool GATE = false>
 __global__ __launch_bounds__(1024) void feat_stream(const StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (GATE && a.redo[0] == 0) return;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -549,16 +681,16 @@ __global__ __launch_bounds__(1024) void feat_stream(const StreamArgs a) {
         // the instantiated (input quads, output tiles) pairs -- api.hip: stream_conv_supported
         const bool nt2 = c.out.quads > 4;
         switch (c.in.quads) {
-            case 1: stream_conv_role<1, 1>(a, c, lds0, j0, rows, T, lane); break;
-            case 2: stream_conv_role<2, 1>(a, c, lds0, j0, rows, T, lane); break;
-            case 3: stream_conv_role<3, 1>(a, c, lds0, j0, rows, T, lane); break;
-            case 4: stream_conv_role<4, 1>(a, c, lds0, j0, rows, T, lane); break;
-            case 5: stream_conv_role<5, 1>(a, c, lds0, j0, rows, T, lane); break;
-            case 6: stream_conv_role<6, 2>(a, c, lds0, j0, rows, T, lane); break;
-            case 7: stream_conv_role<7, 2>(a, c, lds0, j0, rows, T, lane); break;
-            default: if (nt2) stream_conv_role<8, 2>(a, c, lds0, j0, rows, T, lane); else stream_conv_role<8, 1>(a, c, lds0, j0, rows, T, lane); break;
+            case 1: stream_conv_role<1, 1, F16, GATE>(a, c, lds0, j0, rows, T, lane); break;
+            case 2: stream_conv_role<2, 1, F16, GATE>(a, c, lds0, j0, rows, T, lane); break;
+            case 3: stream_conv_role<3, 1, F16, GATE>(a, c, lds0, j0, rows, T, lane); break;
+            case 4: stream_conv_role<4, 1, F16, GATE>(a, c, lds0, j0, rows, T, lane); break;
+            case 5: stream_conv_role<5, 1, F16, GATE>(a, c, lds0, j0, rows, T, lane); break;
+            case 6: stream_conv_role<6, 2, F16, GATE>(a, c, lds0, j0, rows, T, lane); break;
+            case 7: stream_conv_role<7, 2, F16, GATE>(a, c, lds0, j0, rows, T, lane); break;
+            default: if (nt2) stream_conv_role<8, 2, F16, GATE>(a, c, lds0, j0, rows, T, lane); else stream_conv_role<8, 1, F16, GATE>(a, c, lds0, j0, rows, T, lane); break;
         }
-    } else stream_nin_role(a, role - 16, lds0, j0, rows, T, lane);
+    } else stream_nin_role<F16, GATE>(a, role - 16, lds0, j0, rows, T, lane);
 }
 
 }  // namespace dcscn

@@ -713,7 +713,6 @@ void densify_features(dcscn_ctx* h) {
 // reading the whole tensor from channel 0 in its natural channel order (conv3_h / conv3_h8 / conv5_h; conv_nin_h when ALL its sources
 // qualify).  Fixed point over the launch list; runs after finalize_op (it needs to know which launches have a split16 variant).
 void plan_p16(dcscn_ctx* h) {
-    for (int attempt = 0; attempt < 2; ++attempt) {
     const size_t nbuf = h->bufs.size();
     std::vector<char> ok(nbuf, 0), written(nbuf, 0), read(nbuf, 0);
     for (size_t b = 0; b < nbuf; ++b) ok[b] = h->bufs[b].stride > 0;
@@ -775,22 +774,15 @@ void plan_p16(dcscn_ctx* h) {
     }
     // the float32 plan of a flagged image (exec.hip: run_forward): every launch downstream of a split16 launch or of a P16 tensor
     std::vector<char> dirty(nbuf, 0);
-    bool streamed = false;                                        // the streamed kernels cannot be gated per image
     for (Op& op : h->ops) {
-        bool r = op.kind == OP_CONV && op.h16.on;
+        bool r = (op.kind == OP_CONV || op.kind == OP_STREAM || op.kind == OP_TAIL) && op.h16.on;
         for (int b : inputs(op)) r = r || dirty[b];
         for (int k = 0; k < 2; ++k)
             if (op.out_buf[k] >= 0 && !(k == 1 && op.split >= (1 << 29))) r = r || h->bufs[op.out_buf[k]].p16_ok;
         op.h16.rerun = r;
-        if (r) {
-            streamed = streamed || op.kind == OP_STREAM || op.kind == OP_TAIL;
+        if (r)
             for (int k = 0; k < 2; ++k)
                 if (op.out_buf[k] >= 0) dirty[op.out_buf[k]] = 1;
-        }
-    }
-    if (!streamed) return;
-    // a streamed launch behind a split16 launch: no float32 plan can be gated there -- the graph stays on the float32 kernels
-    for (Op& op : h->ops) op.h16.on = false;
     }
 }
 

@@ -173,7 +173,7 @@ struct StreamConv {   // separable 3x3 layer of the stream
     int32_t wp;           // LDS byte offset of the pointwise filter [chunk][tile][64 lanes] float4 (k-steps 0..3)
     int32_t ba;           // LDS byte offset of bias[32], slope[32]
     int32_t to_global;    // 1: the layer stores to `out` channels [0, 4 * out.quads) instead of a ring (B2)
-    int32_t pad_;
+    float inv;            // F16 kernels: 2^-e of the pointwise filter's scale (the bias in the f16 image is multiplied by 2^e)
 };
 struct StreamNinSrc {     // one feature layer as a K-slice of A1 || B1
     StreamRing ring;
@@ -201,6 +201,9 @@ struct StreamArgs {
     StreamRing b1;
     int32_t nin_ba;                        // LDS byte offset of bias[32], slope[32] of [B1 | A1]
     int32_t nb_quads;                      // channel quads of the B1 part
+    float nin_inv;                         // F16 kernel: 2^-e of the A1 || B1 filters' scale
+    int32_t* redo;                         // [0] pass flag, [1 + image] (split16.hpp): raised by the F16 kernel on a non-finite output
+    int32_t redo_check;                    // float32 kernel as the float32 plan: only the flagged images are stored
 };
 
 
@@ -222,10 +225,14 @@ struct TailArgs {
     int32_t b_dww, b_wp, b_bias;    // Up-PS2: depthwise [9][u.quads] float4, pointwise [2][1][64] float4, bias float4
     float c_w[9];         // R-CNN1 depthwise filter
     float c_scale;        // R-CNN1 pointwise scalar
+    float a_inv, b_inv;   // F16 kernel: 2^-e of the Up-PS / Up-PS2 pointwise filters' scales
+    int32_t* redo;        // as StreamArgs
+    int32_t redo_check;
 };
-hipError_t tail_launch(const TailArgs& a, int grid, hipStream_t stream);
+// f16 = the F16 instantiation (a.blob = the f16 image of the filters: pack.hip)
+hipError_t tail_launch(const TailArgs& a, int grid, bool f16, hipStream_t stream);
 void stream_init_kernels();
-hipError_t stream_launch(const StreamArgs& a, int grid, hipStream_t stream);
+hipError_t stream_launch(const StreamArgs& a, int grid, bool f16, hipStream_t stream);
 
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
 int conv_max_fused_dw_nt();

@@ -345,6 +345,38 @@ int finalize_op(dcscn_ctx* h, Op& op) {
     return rc;
 }
 
+// f16 image of one pointwise GEMM of the streamed kernels (feat_stream.hpp: stream_dw_pw, F16), written over its float32 image's slots
+// (same size): `quads` input channel quads in 16-channel chunks, `tiles` output tiles; per chunk PAIR and tile two 1 KB fragments --
+// lane (i = lane & 15: output column 16 n + i, q = lane >> 4) holds k = 8 q + t: t < 4 channel 16 (2p) + 4 q + t, else 16 (2p + 1) + 4 q + t - 4 --
+// hi at slot (2p * tiles + 2n), lo right behind it; an odd last chunk keeps one slot per tile: [hi t 0-3 | lo t 0-3].  get(ci, co) = the
+// weight (0 past the real channels); the weights are multiplied by 2^e.
+template <typename Get>
+static void stream_f16_image(float* dst, int quads, int tiles, const Get& get, int e) {
+    const int chunks = (quads + 3) / 4;
+    uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
+    auto chan = [&](int ch, int q, int t) { return q < std::min(4, quads - 4 * ch) ? 16 * ch + 4 * q + t : -1; };
+    for (int n = 0; n < tiles; ++n)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int q = lane >> 4, co = 16 * n + (lane & 15);
+            for (int p = 0; 2 * p + 1 < chunks; ++p) {
+                uint16_t* hi = d16 + ((size_t)(2 * p * tiles + 2 * n) * 64 + lane) * 8;
+                uint16_t* lo = hi + 64 * 8;
+                for (int t = 0; t < 8; ++t) {
+                    const int ci = chan(2 * p + (t >> 2), q, t & 3);
+                    split16_host(std::ldexp(ci >= 0 ? get(ci, co) : 0.0f, e), &hi[t], &lo[t]);
+                }
+            }
+            if (chunks & 1) {
+                const int ch = chunks - 1;
+                uint16_t* s = d16 + ((size_t)(ch * tiles + n) * 64 + lane) * 8;
+                for (int t = 0; t < 4; ++t) {
+                    const int ci = chan(ch, q, t);
+                    split16_host(std::ldexp(ci >= 0 ? get(ci, co) : 0.0f, e), &s[t], &s[4 + t]);
+                }
+            }
+        }
+}
+
 int pack_tail_stream(dcscn_ctx* h, Op& op) {
     const Op& u1 = op.fused[0];
     const Op& u2 = op.fused[1];
@@ -362,6 +394,7 @@ int pack_tail_stream(dcscn_ctx* h, Op& op) {
     lds += 12 * (4 * kStreamPX + 4) * 4;
     a.ring_bytes = lds;
     std::vector<float> blob;
+    size_t a_wp_base = 0, a_bias_base = 0, b_wp_base = 0, b_bias_base = 0;     // regions the f16 image rewrites
     auto region = [&](size_t floats) { const size_t base = blob.size(); blob.resize(base + floats, 0.0f); lds += (int)floats * 4; return base; };
     // Up-PS
     a.a_dww = lds;
@@ -375,6 +408,7 @@ int pack_tail_stream(dcscn_ctx* h, Op& op) {
     {
         // [chunk][channel tile 0..7][lane] float4 over the 4C conv channels (tile = 2 * phase + half when C > 16)
         const size_t base = region((size_t)2 * 8 * 64 * 4);
+        a_wp_base = base;
         const ColSeg& sg = u1.segs[0];
         const std::vector<float>& pw = tens(sg.w);                    // [1, 1, cin, 4C]: column phase * C + c
         const int tiles = C > 16 ? 2 : 1;
@@ -390,6 +424,7 @@ int pack_tail_stream(dcscn_ctx* h, Op& op) {
     a.a_bias = lds;
     {
         const size_t base = region(8 * 16);                           // [channel tile][16]
+        a_bias_base = base;
         const ColSeg& sg = u1.segs[0];
         const int tiles = C > 16 ? 2 : 1;
         for (int ph = 0; ph < 4; ++ph)
@@ -406,6 +441,7 @@ int pack_tail_stream(dcscn_ctx* h, Op& op) {
     a.b_wp = lds;
     {
         const size_t base = region((size_t)2 * 64 * 4);
+        b_wp_base = base;
         const std::vector<float>& pw = tens(u2.segs[0].w);            // [1, 1, C, 4]
         for (int ch = 0; ch < 2; ++ch)
             for (int lane = 0; lane < 64; ++lane)
@@ -417,6 +453,7 @@ int pack_tail_stream(dcscn_ctx* h, Op& op) {
     a.b_bias = lds;
     {
         const size_t base = region(4);
+        b_bias_base = base;
         const ColSeg& sg = u2.segs[0];
         for (int co = 0; co < 4; ++co) blob[base + co] = sg.b >= 0 ? tens(sg.b)[co] : 0.0f;
     }
@@ -424,7 +461,33 @@ int pack_tail_stream(dcscn_ctx* h, Op& op) {
     if (lds > 160 * 1024) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: tail_stream needs %d bytes of LDS", lds);
     for (int k = 0; k < 9; ++k) a.c_w[k] = tens(rc.dw_w)[k];         // [3, 3, 1, 1]
     a.c_scale = tens(rc.segs[0].w)[0];                               // [1, 1, 1, 1]
-    return upload(h, blob.data(), blob.size() * sizeof(float), (void**)&op.d_w);
+    int urc = upload(h, blob.data(), blob.size() * sizeof(float), (void**)&op.d_w);
+    if (urc) return urc;
+    // the F16 kernel's image (pack_feat_stream does the same for its GEMMs)
+    std::vector<float> blob16 = blob;
+    {
+        const std::vector<float>& pw = tens(u1.segs[0].w);
+        const int tiles = C > 16 ? 2 : 1;
+        const int e = split16_scale_exp(pw.data(), pw.size());
+        auto get = [&](int ci, int co) {
+            const int n = co / 16, ph = n / tiles, cc = 16 * (n % tiles) + co % 16;
+            return ci < cin && ph < 4 && cc < C ? pw[(size_t)ci * 4 * C + ph * C + cc] : 0.0f;
+        };
+        stream_f16_image(&blob16[a_wp_base], cin / 4, 8, get, e);
+        for (int k = 0; k < 8 * 16; ++k) blob16[a_bias_base + k] = std::ldexp(blob[a_bias_base + k], e);
+        a.a_inv = std::ldexp(1.0f, -e);
+    }
+    {
+        const std::vector<float>& pw = tens(u2.segs[0].w);
+        const int e = split16_scale_exp(pw.data(), pw.size());
+        auto get = [&](int ci, int co) { return ci < C && co < 4 ? pw[(size_t)ci * 4 + co] : 0.0f; };
+        stream_f16_image(&blob16[b_wp_base], C / 4, 1, get, e);
+        for (int k = 0; k < 4; ++k) blob16[b_bias_base + k] = std::ldexp(blob[b_bias_base + k], e);
+        a.b_inv = std::ldexp(1.0f, -e);
+    }
+    urc = upload(h, blob16.data(), blob16.size() * sizeof(float), &op.h16.d_w);
+    op.h16.on = urc == DCSCN_OK;
+    return urc;
 }
 
 int pack_feat_stream(dcscn_ctx* h, Op& op) {
@@ -453,6 +516,7 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
     a.ring_bytes = lds;
 
     std::vector<float> blob;
+    std::vector<size_t> nin_base(L), wp_base(L), ba_base(L);        // blob offsets (floats) of the regions the f16 image rewrites
     auto tens = [&](int id) -> const std::vector<float>& { return h->tensors[id].data; };
     // --- LDS image: A1 || B1 slices, then the depthwise filters ---
     const Op& nin = op.fused[L + 1];
@@ -467,6 +531,7 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
         s.last_ql = s.ring.quads - 4 * (s.chunks - 1);
         s.w = lds;
         const size_t base = blob.size();
+        nin_base[i] = base;
         blob.resize(base + (size_t)s.chunks * 2 * 64 * 4, 0.0f);
         for (int ch = 0; ch < s.chunks; ++ch)
             for (int n = 0; n < 2; ++n)
@@ -522,6 +587,7 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
         StreamConv& cv = a.conv[i];
         cv.wp = lds;
         size_t base = blob.size();
+        wp_base[i] = base;
         blob.resize(base + (size_t)chunks * tiles * 64 * 4, 0.0f);
         const std::vector<float>& pw = tens(sg.w);              // [1, 1, cin, cout]
         for (int ch = 0; ch < chunks; ++ch)
@@ -534,6 +600,7 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
         lds += chunks * tiles * 64 * 16;
         cv.ba = lds;
         base = blob.size();
+        ba_base[i] = base;
         blob.resize(base + 64, 0.0f);
         bias_alpha(src, sg, 0, base);
         lds += 256;
@@ -619,7 +686,55 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
         for (int co = 0; co < sg.cout; ++co) blob[a.first_w + 12 + co] = tens(sg.w)[co];      // [1, 1, 1, C1]
         bias_alpha(c1, sg, 0, (size_t)a.first_w + 44);
     }
-    return upload(h, blob.data(), blob.size() * sizeof(float), (void**)&op.d_w);
+    int rc = upload(h, blob.data(), blob.size() * sizeof(float), (void**)&op.d_w);
+    if (rc) return rc;
+    // --- the F16 kernel's image: the same blob with the pointwise and A1 || B1 filters as f16 (hi, lo) fragments scaled by 2^e per GEMM,
+    // the convs' biases times 2^e (they are the first MFMA's C operand); 2^-e goes to the kernel arguments ---
+    std::vector<float> blob16 = blob;
+    for (int i = 0; i < L; ++i) {
+        const bool is_b2 = i == L - 1;
+        const Op& src = is_b2 ? op.fused[L + 2] : op.fused[2 + i];
+        const ColSeg& sg = src.segs[0];
+        const int cin = is_b2 ? nb : h->sched[i], cout = sg.cout;
+        const std::vector<float>& pw = tens(sg.w);
+        const int e = split16_scale_exp(pw.data(), (size_t)cin * cout);
+        auto get = [&](int ci, int co) { return ci < cin && co < cout ? pw[(size_t)ci * cout + co] : 0.0f; };
+        stream_f16_image(&blob16[wp_base[i]], pad4(cin) / 4, (cout + 15) / 16, get, e);
+        for (int k = 0; k < 32; ++k) blob16[ba_base[i] + k] = std::ldexp(blob[ba_base[i] + k], e);
+        a.conv[i].inv = std::ldexp(1.0f, -e);
+    }
+    {
+        auto ninw = [&](int layer_base, int ci, int v) -> float {
+            const ColSeg* sg = nullptr;
+            int co = 0;
+            if (v < pad4(nb)) { if (v < nb) { sg = &sb; co = v; } }
+            else if (v - pad4(nb) < na) { sg = &sa; co = v - pad4(nb); }
+            if (!sg) return 0.0f;
+            const int cols = (int)h->tensors[sg->w].shape.back();
+            float w = tens(sg->w)[(size_t)(layer_base + ci) * cols + sg->col0 + co];
+            if (sg->dw1 >= 0) w = tens(sg->dw1)[layer_base + ci] * w;
+            return w;
+        };
+        std::vector<float> all;
+        int cb = 0;
+        for (int i = 0; i < L; ++i) {
+            for (int ci = 0; ci < h->sched[i]; ++ci)
+                for (int v = 0; v < 32; ++v) all.push_back(ninw(cb, ci, v));
+            cb += h->sched[i];
+        }
+        const int e = split16_scale_exp(all.data(), all.size());
+        cb = 0;
+        for (int i = 0; i < L; ++i) {
+            const int C = h->sched[i];
+            auto get = [&](int ci, int v) { return ci < C ? ninw(cb, ci, v) : 0.0f; };
+            stream_f16_image(&blob16[nin_base[i]], a.nin[i].ring.quads, 2, get, e);
+            cb += C;
+        }
+        a.nin_inv = std::ldexp(1.0f, -e);
+    }
+    rc = upload(h, blob16.data(), blob16.size() * sizeof(float), &op.h16.d_w);
+    op.h16.on = rc == DCSCN_OK;
+    return rc;
 }
 
 }  // namespace dcscn_impl

@@ -76,7 +76,7 @@ __device__ __forceinline__ void tail_load_role(const TailArgs& a, const StreamAr
 // ---- Up-PS on 16 pixels, all four sub-pixel phases ------------------------------------------------------------------------
 // (splitting by phase instead would make four waves repeat the same depthwise; here a lane owns ONE pixel, its window is 3
 // reads per row, and the wave runs the whole [4C x C] pointwise: 8 channel tiles of accumulators)
-template <int QI>
+template <int QI, bool F16>
 __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArgs& geo, int seg, unsigned lds0, int j0, int rows, int T, int lane) {
     const int j = lane & 15, q = lane >> 4;
     constexpr unsigned in_px = (unsigned)(QI | 1) * 16u, in_row = (unsigned)kStreamRowPx * in_px;
@@ -97,9 +97,15 @@ __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArg
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) rowb[dy] = lds0 + a.in.off + (unsigned)((g + 2 + dy) % 3) * in_row + (unsigned)px * in_px;
                 f32x4 bs[8];
+                if constexpr (!F16) {
 #pragma unroll
-                for (int n = 0; n < 8; ++n) bs[n] = stream_ld(lds0 + a.a_bias + (unsigned)(n * 4 + q) * 16u);
-                stream_dw_pw<QI, 8, 1>(acc, bs, lds0, rowb, a.a_dww, a.a_wp, q, lane);
+                    for (int n = 0; n < 8; ++n) bs[n] = stream_ld(lds0 + a.a_bias + (unsigned)(n * 4 + q) * 16u);
+                }
+                stream_dw_pw<QI, 8, 1, F16>(acc, bs, lds0, rowb, a.a_dww, a.a_wp, q, lane, lds0 + a.a_bias + (unsigned)q * 16u);
+                if constexpr (F16) {
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) acc[0][n] = acc[0][n] * a.a_inv;
+                }
                 const int cx = ri.sx + px;
                 keep = cx >= 0 && cx < a.W;
                 inside = ri.sx >= 0 && ri.sx + kStreamPX <= a.W;
@@ -124,7 +130,7 @@ __device__ __forceinline__ void tail_up1_role(const TailArgs& a, const StreamArg
 }
 
 // ---- Up-PS2 on U row 2g + r2, pixels 48 * half .. + 47 ------------------------------------------------------------------
-template <int QU>
+template <int QU, bool F16>
 __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArgs& geo, int r2, int half, unsigned lds0, int j0, int rows, int T, int lane) {
     const int j = lane & 15, q = lane >> 4;
     constexpr unsigned u_px = (unsigned)(QU | 1) * 16u, u_row = (unsigned)kTailURowPx * u_px;
@@ -143,8 +149,12 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
                     rowb[dy] = lds0 + a.u.off + (unsigned)((ur - 1 + dy + kTailUSlots) % kTailUSlots) * u_row + (unsigned)(kStreamPX * half + 3 * j) * u_px;
-                const f32x4 bs[1] = {stream_ld(lds0 + a.b_bias)};
-                stream_dw_pw<QU, 1>(acc, bs, lds0, rowb, a.b_dww, a.b_wp, q, lane);
+                const f32x4 bs[1] = {F16 ? kStreamZero : stream_ld(lds0 + a.b_bias)};
+                stream_dw_pw<QU, 1, kStreamMT, F16>(acc, bs, lds0, rowb, a.b_dww, a.b_wp, q, lane, lds0 + a.b_bias);
+                if constexpr (F16) {
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) acc[m][0] = acc[m][0] * a.b_inv;
+                }
 #pragma unroll
                 for (int m = 0; m < kStreamMT; ++m) {
                     const int cx2 = 2 * ri.sx + kStreamPX * half + 3 * j + m;
@@ -175,6 +185,7 @@ __device__ __forceinline__ void tail_up2_role(const TailArgs& a, const StreamArg
 }
 
 // ---- R-CNN1 + residual on HR rows 4g + 2c + {0, 1} -----------------------------------------------------------------------
+template <bool F16, bool GATE>
 __device__ __forceinline__ void tail_rec_role(const TailArgs& a, const StreamArgs& geo, int c, unsigned lds0, int j0, int rows, int T, int lane) {
     typedef const __attribute__((address_space(3))) float* lds_f1;
     StreamCursor cur, pcur;
@@ -202,7 +213,7 @@ __device__ __forceinline__ void tail_rec_role(const TailArgs& a, const StreamArg
         fetch(g + 1, nres);
         if (live) {
             const StreamRow ri = stream_row(geo, j0, cur, g);
-            if (ri.store && STREAM_ABL != 9 && STREAM_ABL != 13) {
+            if (ri.store && STREAM_ABL != 9 && STREAM_ABL != 13 && (!GATE || a.redo[1 + ri.img] != 0)) {
                 const int vr0 = 4 * g + 2 * c;                  // first output row in V-row numbering
                 const int cx0 = 4 * ri.sx + 3 * lane;           // first of the lane's three HR columns
                 float v[4][5];
@@ -222,8 +233,11 @@ __device__ __forceinline__ void tail_rec_role(const TailArgs& a, const StreamArg
 #pragma unroll
                             for (int dx = 0; dx < 3; ++dx) s = fmaf(a.c_w[dy * 3 + dx], v[e + dy][k + dx], s);
                         const int cx = cx0 + k;
-                        if (cx >= 4 * ri.ux0 && cx < 4 * ri.ux1)
-                            a.y[((size_t)ri.img * 4 * a.H + 4 * ri.r + 2 * c + e) * W4 + cx] = s * a.c_scale + res[e][k];
+                        if (cx >= 4 * ri.ux0 && cx < 4 * ri.ux1) {
+                            const float out = s * a.c_scale + res[e][k];
+                            if (F16 && !(fabsf(out) <= 3.0e38f) && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }    // not finite: the image goes to the float32 plan
+                            a.y[((size_t)ri.img * 4 * a.H + 4 * ri.r + 2 * c + e) * W4 + cx] = out;
+                        }
                     }
             }
         }
@@ -236,8 +250,11 @@ __device__ __forceinline__ void tail_rec_role(const TailArgs& a, const StreamArg
     }
 }
 
+// F16: the two pointwise GEMMs on the f16 matrix pipe (feat_stream.hpp: stream_dw_pw); false: f32 MFMAs, and the float32 plan (redo_check)
+template <bool F16, bool GATE = false>
 __global__ __launch_bounds__(640) void tail_stream(const TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (GATE && a.redo[0] == 0) return;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
@@ -259,9 +276,9 @@ __global__ __launch_bounds__(640) void tail_stream(const TailArgs a) {
     constexpr int kRole[10] = {4, 1, 2, 3, 5, 8, 6, 7, 0, 9};
     const int role = kRole[wave];
     if (role == 0) tail_load_role(a, geo, lds0, j0, rows, T, lane);
-    else if (role <= 3) tail_up1_role<8>(a, geo, role - 1, lds0, j0, rows, T, lane);      // instantiated for 32 -> 4 x 32 -> 4 channels (api.hip: fuse_tail_stream)
-    else if (role <= 7) tail_up2_role<8>(a, geo, (role - 4) >> 1, (role - 4) & 1, lds0, j0, rows, T, lane);
-    else tail_rec_role(a, geo, role - 8, lds0, j0, rows, T, lane);
+    else if (role <= 3) tail_up1_role<8, F16>(a, geo, role - 1, lds0, j0, rows, T, lane);      // instantiated for 32 -> 4 x 32 -> 4 channels (api.hip: fuse_tail_stream)
+    else if (role <= 7) tail_up2_role<8, F16>(a, geo, (role - 4) >> 1, (role - 4) & 1, lds0, j0, rows, T, lane);
+    else tail_rec_role<F16, GATE>(a, geo, role - 8, lds0, j0, rows, T, lane);
 }
 
 }  // namespace dcscn
