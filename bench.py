@@ -245,7 +245,8 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    per_op_ms = eng.profile()         # averaged over the timed steps
+    per_op_ms = eng.profile(with_float32_plan=True)         # averaged over the timed steps
+    f32_plan_ms = per_op_ms.pop()     # the gated float32 launches behind the pass (empty unless an image left the f16 range)
     eng.set_option("profile", 0)
     if world > 1:
         t = torch.tensor([elapsed], device="cpu" if share_gpu else "cuda", dtype=torch.float64)
@@ -364,7 +365,7 @@ def main():
                 "parallelism": "image-shard x%d, no collective" % world,
                 "flop_per_lr_pixel_direct_form": 2 * total_macs,
                 "graph": graph,
-                "arithmetic": "split16 (include/dcscn.h)" if on_f16 else "f32 kernels (split16 = 0)",
+                "arithmetic": "split16, tensors between its launches pre-split (p16; include/dcscn.h)" if on_f16 else "f32 kernels (split16 = 0)",
             },
             "roofline": {
                 "kernel": "%s 3x3 (%s), %d launches/pass" % ("+".join(dom_kernels), "v_mfma_f32_16x16x32_f16, f16 hi/lo x 3 products" if on_f16
@@ -397,7 +398,7 @@ def main():
                          "per second of its own launch time (HIP events on the launch stream); frac = matrix-pipe utilisation."),
                 "kernel_ms_per_step": round(dom_ms, 4),
             },
-            "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_kernel.items())},
+            "kernel_ms_per_step": dict({k: round(v, 4) for k, v in sorted(per_kernel.items())}, float32_plan_gated=round(f32_plan_ms, 4)),
             "whole_net_tflops_direct_form_equivalent": round(2.0 * total_macs * lr_pixels / (kernel_ms * 1e-3) / 1e12, 3) if kernel_ms else None,
         }
         if strong_leg is not None:
@@ -475,6 +476,33 @@ def main():
                 eng.set_option("graph_replay", 0)
             except Exception as exc:
                 result["graph_replay"] = {"error": str(exc)}
+        if world == 1 and on_f16 and not args.no_extra_graph:
+            # beside the headline: the same engine with float32 tensors between the split16 launches (p16 = 0: the r04 data path)
+            try:
+                y_p16 = y.clone()
+                n_p16 = eng.num_p16_tensors()
+                eng.set_option("p16", 0)
+                for _ in range(max(args.warmup, 1)):
+                    step()
+                eng.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                eng.synchronize()
+                el5 = time.perf_counter() - t1
+                result["float32_tensors"] = {
+                    "value": round(lr_pixels * args.steps / el5 / 1e6, 4), "unit": "LR Mpix/s",
+                    "ms_per_step": round(el5 / args.steps * 1e3, 4),
+                    "bit_identical_to_headline": bool(torch.equal(y, y_p16)),
+                    "p16_tensors_in_headline": n_p16,
+                    "note": "dcscn_set_option(p16, 0): float32 NHWC tensors between the split16 launches, split in every consumer (r04); the headline "
+                            "keeps them pre-split (csrc/p16.hpp): same products in the same order",
+                }
+                eng.set_option("p16", 1)
+                step()
+                eng.synchronize()
+            except Exception as exc:
+                result["float32_tensors"] = {"error": str(exc)}
         if world == 1 and on_f16 and not args.no_extra_graph:
             # beside the headline: the same engine on the pure f32 kernels (split16 = 0), same inputs, timed the same way
             try:

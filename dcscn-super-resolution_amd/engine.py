@@ -479,12 +479,13 @@ class Engine:
                                                      int(n_ensemble)))
         return y
 
-    def profile(self):
-        """Per-launch milliseconds of the last forward (needs set_option('profile', 1))."""
+    def profile(self, with_float32_plan=False):
+        """Per-launch milliseconds of the last forward (needs set_option('profile', 1)).  with_float32_plan: one more entry, the gated
+        float32 launches behind every split16 pass (they exit at once unless an image left the f16 range; include/dcscn.h "split16")."""
         n = self._lib.dcscn_num_ops(self._h)
-        ms = (ctypes.c_double * n)()
-        self._check(self._lib.dcscn_get_profile(self._h, ms, n))
-        return list(ms)
+        ms = (ctypes.c_double * (n + 1))()
+        self._check(self._lib.dcscn_get_profile(self._h, ms, n + 1))
+        return list(ms) if with_float32_plan else list(ms)[:n]
 
     def debug_digests(self):
         """Workspace checksum behind every launch of the last pass + one of its output (needs set_option('debug_digest', 1))."""

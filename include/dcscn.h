@@ -273,7 +273,8 @@ int dcscn_sr_rgb(dcscn_handle h, const uint8_t* rgb, const uint8_t* rgb_upscaled
 
 /* Per-launch (dcscn_op_info order) device milliseconds, summed over sub-batches and averaged over
  * the forwards run with the profile option on since the previous call (which this call resets);
- * `ms` receives min(capacity, num_ops) entries.  Synchronises the device. */
+ * `ms` receives min(capacity, num_ops + 1) entries; entry num_ops is the float32 plan behind the split16 passes (the gated float32
+ * launches, see "split16": microseconds unless an image left the f16 range).  Synchronises the device. */
 int dcscn_get_profile(dcscn_handle h, double* ms, int capacity);
 
 /* Debug aid (no reference counterpart): with dcscn_set_option("debug_digest", 1) every launch of a forward is followed by a
