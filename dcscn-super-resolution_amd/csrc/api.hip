@@ -166,6 +166,7 @@ int dcscn_finalize(dcscn_handle h) {
     fuse_tail_stream(h);
     fuse_feat_stream(h);
     densify_features(h);
+    fuse_feat3_stream(h);
     for (Op& op : h->ops) {
         int rc = finalize_op(h, op);
         if (rc) return rc;
@@ -210,7 +211,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
     const bool s16 = op_on_split16(h, op);
     const bool h8 = op_takes_h8(h, op);                          // (the predicate launch_op itself uses)
-    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (s16 ? (op.shape.nin ? "conv_nin_h" : op.fold_s > 0 ? "conv5_h" : h8 ? "conv3_h8" : "conv3_h") : op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : "depthwise");
+    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (s16 ? (op.shape.nin ? "conv_nin_h" : op.fold_s > 0 ? "conv5_h" : h8 ? "conv3_h8" : "conv3_h") : op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : op.kind == OP_STREAM3 ? (s16 ? "feat3_stream" : "layer by layer") : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
     out->out_channels = op.cout;
@@ -277,6 +278,11 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "stream_features")) {
         if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the stream_features option must be set before dcscn_finalize");
         h->stream_features = value != 0;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "stream_dense")) {
+        if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the stream_dense option must be set before dcscn_finalize");
+        h->stream_dense = value != 0;
         return DCSCN_OK;
     }
     if (!strcmp(key, "dense_features")) {

@@ -74,7 +74,7 @@ static P16Desc p16_desc(const dcscn_ctx* h, int id) {
 }
 
 bool op_on_split16(const dcscn_ctx* h, const Op& op) {
-    if (op.kind == OP_STREAM || op.kind == OP_TAIL) return h->split16 && op.h16.on && (h->split16_mask & 1);      // the F16 instantiation of the streamed kernels
+    if (op.kind == OP_STREAM || op.kind == OP_TAIL || op.kind == OP_STREAM3) return h->split16 && op.h16.on && (h->split16_mask & 1);      // the F16 instantiation of the streamed kernels
     return op.kind == OP_CONV && h->split16 && op.h16.on && (h->split16_mask & (op.shape.nin ? 2 : 1));
 }
 
@@ -100,6 +100,42 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
     const int Hr = H * op.res, Wr = W * op.res;
     int32_t* const redo_flags = reinterpret_cast<int32_t*>(static_cast<char*>(h->arena) + h->redo_off);
     const bool stream16 = !redo && op_on_split16(h, op);          // streamed kernels: the F16 instantiation on its own filter image
+    if (op.kind == OP_STREAM3) {
+        if (!stream16) {
+            // split16 = 0, or the float32 plan of a flagged image: the layers one by one on their own float32 kernels
+            for (const Op& sub : op.fused) {
+                const int rc = launch_op(h, sub, nb, H, W, x, x2, y, stream, redo);
+                if (rc) return rc;
+            }
+            return DCSCN_OK;
+        }
+        Stream3Args a = op.stream3;
+        a.x = x;
+        a.blob = op.d_w;
+        a.N = nb; a.H = H; a.W = W;
+        a.halo = a.L;                                     // receptive-field radius of the fused chain
+        if (W <= kStreamPX) { a.n_strips = 1; a.useful_w = W; }
+        else { a.useful_w = kStreamPX - 2 * a.halo; a.n_strips = (W + a.useful_w - 1) / a.useful_w; }
+        const int64_t cols = (int64_t)nb * a.n_strips;
+        const int want = (int)std::max<int64_t>(1, (512 + cols - 1) / cols);
+        a.useful_h = std::max(32, (H + want - 1) / want);
+        a.n_blocks = (H + a.useful_h - 1) / a.useful_h;
+        a.rows_c = a.n_blocks == 1 ? H : a.useful_h + 2 * a.halo;
+        a.n_jobs = (int)(cols * a.n_blocks);
+        a.jobs_per_wg = (a.n_jobs + h->n_cus - 1) / h->n_cus;
+        const int grid = (a.n_jobs + a.jobs_per_wg - 1) / a.jobs_per_wg;
+        for (size_t i = 0; i < op.extra_out.size(); ++i) {
+            const int id = op.extra_out[i];
+            S3Out& o = a.out[i];
+            o.ptr = buf_ptr(h, id);
+            o.stride = h->bufs[id].stride;
+            o.width = h->bufs[id].stride;
+            o.p16 = h->bufs[id].p16 ? p16_desc(h, id) : P16Desc{nullptr, 0, 0, 0};
+        }
+        a.redo = redo_flags;
+        HIP_TRY(h, stream3_launch(a, grid, stream));
+        return DCSCN_OK;
+    }
     if (op.kind == OP_TAIL) {
         TailArgs a = op.tail;
         a.c2 = buf_ptr(h, op.in_buf);

@@ -1,0 +1,253 @@
+// feat3_stream: the feature extractor of the NON-separable narrow nets (c-DCSCN: CNN1 .. CNNL, 3x3 SAME convs + bias + PReLU of at most 32
+// channels, DCSCN.py:240-256 with tf_graph.py:104-153) as ONE row-streamed launch -- VERDICT r03 item 4 / r04 item 3.
+//
+// Layer by layer these nets are bound by HBM round trips and launch overheads (seven launches of 0.08 - 0.21 ms for ~0.1 ms of matrix
+// work); here a workgroup owns a 48-pixel column strip and walks down its rows like feat_stream.hpp (same jobs, strips, row blocks,
+// separator rows, two barriers per step), every layer keeps a three-row ring of its output in LDS, and every layer's rows also go to
+// global memory ONCE, for the 1x1 GEMM A1 || B1 that follows (as P16 tensors or float32, whatever plan_p16 gave the tensor).
+//
+//   * rings hold P16 units (p16.hpp): per pixel and channel octet [hi 8 halfs | lo 8 halfs], written by the producing wave's epilogue
+//     (p16_unit: split + v_permlane16_swap) -- a consumer's B operand is two ds_read_b128, no VALU.
+//   * a conv is a K = 9 * Cin implicit GEMM on v_mfma_f32_16x16x32_f16 with the (tap, octet) pairs packed four to an instruction (conv3_h's
+//     packed tail, for every chunk): lane group q of step s multiplies pair 4 s + q; ceil(9 * octets / 4) = 3 / 5 / 7 / 9 steps.
+//     Three products per accumulator (split16.hpp), filters f16 (hi, lo) scaled by 2^e, bias * 2^e as the first C operand.
+//   * a wave = (conv, 16-channel output tile); its filter fragments -- at most 9 steps x (hi, lo) = 72 registers -- live in REGISTERS for the
+//     whole launch (the dense filters of the net are 140 KB as fragments: they do not fit beside the rings, and nothing else needs them).
+//     Pixel tile m of lane column j is pixel 3 j + m, as in feat_stream.
+//   * wave -> SIMD placement balances the MFMA counts (pack.hip: pack_feat3_stream); CNN1 (one input channel) is VALU work on its own wave.
+//
+// The float32 plan of a flagged image, and split16 = 0, run the layers one by one on their own kernels (exec.hip: Op::fused).
+#pragma once
+#include "feat_stream.hpp"
+#include "p16.hpp"
+
+namespace dcscn {
+
+__device__ __forceinline__ StreamArgs s3_geometry(const Stream3Args& a) {
+    StreamArgs g{};                                            // stream_row only looks at the job geometry
+    g.H = a.H; g.W = a.W;
+    g.n_strips = a.n_strips; g.useful_w = a.useful_w; g.halo = a.halo;
+    g.n_blocks = a.n_blocks; g.useful_h = a.useful_h; g.rows_c = a.rows_c;
+    return g;
+}
+
+// one unit per lane (tile `tile`, lane group q: octet 2 tile + (q >> 1), part q & 1) of pixel (img, r, cx) -> the layer's global tensor
+__device__ __forceinline__ void s3_store_global(const S3Out& o, long long pix, int tile, int q, const u32x4 unit, const f32x4 v) {
+    if (o.p16.base) {
+        const int octet = 2 * tile + (q >> 1);
+        if (octet < o.p16.octs) {
+            const int chunk = octet >> 2, rec = p16_rec_bytes(o.p16.octs, chunk);
+            *reinterpret_cast<u32x4*>(o.p16.base + (long long)chunk * o.p16.plane + 128 + pix * rec + (octet & 3) * 32 + (q & 1) * 16) = unit;
+        }
+    } else if (16 * tile + 4 * q < o.width) {
+        *reinterpret_cast<f32x4*>(o.ptr + pix * o.stride + 16 * tile + 4 * q) = v;
+    }
+}
+
+// ---- CNN1: Y -> 3x3 conv to C1 <= 32 channels, bias, PReLU; VALU only ---------------------------------------------------
+__device__ __forceinline__ void s3_first_role(const Stream3Args& a, const StreamArgs& geo, unsigned lds0, int j0, int rows, int T, int lane) {
+    const int j = lane & 15, q = lane >> 4;
+    f32x4 w9[2][9], bs[2], al[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w9[n][t] = *reinterpret_cast<const f32x4*>(a.blob + a.first_w + t * 32 + n * 16 + 4 * q);
+        bs[n] = *reinterpret_cast<const f32x4*>(a.blob + a.first_w + 288 + n * 16 + 4 * q);
+        al[n] = *reinterpret_cast<const f32x4*>(a.blob + a.first_w + 320 + n * 16 + 4 * q);
+    }
+    const float m1 = opaque_minus_one();
+    const h2 zero2 = p16_opaque_zero2();
+    const unsigned out_px = (unsigned)a.first_out.px, out_row = (unsigned)kStreamRowPx * out_px;
+    float xw[4][5];
+    StreamCursor lc, cc;
+    auto load_row = [&](int gs, float (&dst)[5]) DCSCN_INL {
+        const bool in = gs >= 0 && gs < rows;
+        const StreamRow ri = stream_row(geo, j0, lc, in ? gs : 0);
+        const bool live = in && !ri.zero;
+        const float* row = a.x + ((size_t)ri.img * a.H + (live ? ri.r : 0)) * a.W;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int cx = ri.sx + 3 * j + k - 1;
+            dst[k] = live && cx >= 0 && cx < a.W ? row[cx] : 0.0f;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < 5; ++k) xw[1][k] = 0.0f;
+    load_row(0, xw[2]);
+    load_row(1, xw[3]);
+    for (int t = 0; t < T; ++t) {
+        const int g = t;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) xw[s][k] = xw[s + 1][k];
+        load_row(g + 2, xw[3]);
+        const bool live = g < rows;
+        u32x4 unit[kStreamMT][2];
+        if (live) {
+            const StreamRow ri = stream_row(geo, j0, cc, g);
+            float chk = 0.0f;
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m) {
+                const int cx = ri.sx + 3 * j + m;
+                const bool ok = !ri.zero && cx >= 0 && cx < a.W;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    f32x4 s = kStreamZero;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) s += w9[n][dy * 3 + dx] * xw[dy][m + dx];
+                    f32x4 v = stream_prelu(bs[n] + s, al[n]);
+                    v = ok ? v : kStreamZero;
+                    unit[m][n] = p16_unit(v, m1, chk, zero2);
+                    if (ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(a.out[0], ((long long)ri.img * a.H + ri.r) * a.W + cx, n, q, unit[m][n], v);
+                }
+            }
+            if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
+        }
+        stream_barrier();
+        if (live) {
+            const unsigned wb = lds0 + a.first_out.off + (unsigned)(g % 3) * out_row + (unsigned)(3 * j + 1) * out_px + (unsigned)q * 16u;
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    if (2 * n + (q >> 1) < a.first_out.octs) stream_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, __builtin_bit_cast(f32x4, unit[m][n]));
+        }
+        stream_barrier();
+    }
+}
+
+// ---- CNN2 .. CNNL: one 16-channel output tile of a 3x3 conv from the predecessor's ring --------------------------------
+// OCTS = channel octets of the input ring (compile time: the step count, every LDS offset an immediate or one register per step)
+template <int OCTS>
+__device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamArgs& geo, int ci, int tile, unsigned lds0, int j0, int rows, int T, int lane) {
+    const S3Conv& c = a.conv[ci];
+    const S3Out& og = a.out[ci + 1];
+    constexpr int STEPS = (9 * OCTS + 3) / 4;
+    constexpr unsigned IN_PX = (unsigned)(2 * OCTS + 1) * 16u, IN_ROW = (unsigned)kStreamRowPx * IN_PX;
+    const int j = lane & 15, q = lane >> 4;
+    // filter fragments of this wave's tile: [step][tile][hi | lo][64 lanes][8 halfs] in the blob
+    h8 fh[STEPS], fl[STEPS];
+    {
+        const char* wsrc = reinterpret_cast<const char*>(a.blob + c.w_off);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            fh[s] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((s * c.tiles + tile) * 2 + 0) * 64 + lane) * 16);
+            fl[s] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((s * c.tiles + tile) * 2 + 1) * 64 + lane) * 16);
+        }
+    }
+    const f32x4 bs = *reinterpret_cast<const f32x4*>(a.blob + c.ba_off + tile * 16 + 4 * q);          // bias * 2^e
+    const f32x4 am1 = *reinterpret_cast<const f32x4*>(a.blob + c.ba_off + 32 + tile * 16 + 4 * q);    // slope - 1
+    // step s, lane group q: pair p = 4 s + q = (tap, octet) with tap = p / OCTS.  For OCTS >= 2 the four lane groups of a step see at most two
+    // taps -- tap0 = 4 s / OCTS below the lane-group threshold `thr`, tap0 + 1 from it on -- so row, column and octet offset are compile-time
+    // constants selected by one compare; pairs past the last (tap 9) read valid units of tap 8 against zero filters.  OCTS = 1: four taps per
+    // step, one offset register per step.
+    unsigned soff[OCTS == 1 ? STEPS : 1];
+    unsigned dyp = 0;
+    if constexpr (OCTS == 1) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            int tap = 4 * s + q;
+            tap = tap > 8 ? 8 : tap;
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            soff[s] = (unsigned)dx * IN_PX;
+            dyp |= (unsigned)dy << (2 * s);
+        }
+    } else soff[0] = (unsigned)q * 32u;
+    const float m1 = opaque_minus_one();
+    const h2 zero2 = p16_opaque_zero2();
+    const unsigned out_px = (unsigned)c.out.px, out_row = (unsigned)kStreamRowPx * out_px;
+    StreamCursor cur;
+    for (int t = 0; t < T; ++t) {
+        const int g = t - c.lag;
+        const bool live = g >= 0 && g < rows;
+        u32x4 unit[kStreamMT];
+        bool zero_row = true;
+        if (live) {
+            const StreamRow ri = stream_row(geo, j0, cur, g);
+            zero_row = ri.zero;
+            if (!ri.zero) {
+                unsigned rb[3];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) rb[dy] = lds0 + c.in.off + (unsigned)((g + 5 + dy) % 3) * IN_ROW + (unsigned)(3 * j) * IN_PX;   // rows g-1, g, g+1
+                f32x4 acc[kStreamMT];
+                static_for<0, STEPS>([&](auto s_) DCSCN_INL {
+                    constexpr int s = decltype(s_)::value;
+                    unsigned base;
+                    if constexpr (OCTS == 1) {
+                        const unsigned dy = (dyp >> (2 * s)) & 3u;
+                        base = (dy == 0 ? rb[0] : dy == 1 ? rb[1] : rb[2]) + soff[s];
+                    } else {
+                        constexpr int p0 = 4 * s, tap0 = p0 / OCTS, thr = OCTS * (tap0 + 1) - p0;       // lane groups q >= thr are on tap0 + 1
+                        constexpr int ta = tap0 > 8 ? 8 : tap0, tb = tap0 + 1 > 8 ? 8 : tap0 + 1;
+                        constexpr int offa = (ta % 3) * (int)IN_PX + (p0 - OCTS * tap0) * 32, offb = (tb % 3) * (int)IN_PX + (p0 - OCTS * (tap0 + 1)) * 32;
+                        if constexpr (thr > 3) base = rb[ta / 3] + (unsigned)offa + soff[0];
+                        else base = (q >= thr ? rb[tb / 3] + (unsigned)offb : rb[ta / 3] + (unsigned)offa) + soff[0];
+                    }
+                    // the three pixel tiles' products interleaved: an accumulator is touched every third MFMA (back to back they wait for each other)
+                    h8 xh[kStreamMT], xl[kStreamMT];
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) {
+                        xh[m] = __builtin_bit_cast(h8, stream_ld(base + (unsigned)m * IN_PX));
+                        xl[m] = __builtin_bit_cast(h8, stream_ld(base + (unsigned)m * IN_PX + 16u));
+                    }
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s], xh[m], s == 0 ? bs : acc[m], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xl[m], acc[m], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xh[m], acc[m], 0, 0, 0);
+                });
+                float chk = 0.0f;
+#pragma unroll
+                for (int m = 0; m < kStreamMT; ++m) {
+                    const int cx = ri.sx + 3 * j + m;
+                    f32x4 v = stream_prelu(acc[m] * c.inv, am1);
+                    v = cx >= 0 && cx < a.W ? v : kStreamZero;      // SAME padding: columns outside the image are zero in every ring
+                    unit[m] = p16_unit(v, m1, chk, zero2);
+                    if (ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(og, ((long long)ri.img * a.H + ri.r) * a.W + cx, tile, q, unit[m], v);
+                }
+                if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
+            }
+        }
+        stream_barrier();
+        if (live && c.out.px > 0 && 2 * tile + (q >> 1) < c.out.octs) {
+            const unsigned wb = lds0 + c.out.off + (unsigned)(g % 3) * out_row + (unsigned)(3 * j + 1) * out_px + (unsigned)tile * 64u + (unsigned)q * 16u;
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m) stream_st(wb + (unsigned)m * out_px, zero_row ? kStreamZero : __builtin_bit_cast(f32x4, unit[m]));
+        }
+        stream_barrier();
+    }
+}
+
+// one workgroup = n_waves waves (pack.hip: the role table), one per CU (the rings take most of the LDS)
+__global__ __launch_bounds__(640) void feat3_stream(const Stream3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    {
+        f32x4* s4 = reinterpret_cast<f32x4*>(smem);
+        for (int i = tid; i < a.ring_bytes / 16; i += blockDim.x) s4[i] = kStreamZero;
+        __syncthreads();
+    }
+    const StreamArgs geo = s3_geometry(a);
+    const int j0 = blockIdx.x * a.jobs_per_wg;
+    const int j1 = min(a.n_jobs, j0 + a.jobs_per_wg);
+    const int rows = (j1 - j0) * (a.rows_c + 1);
+    const int T = rows + a.total_lag;
+    const int ci = a.role_conv[wave], tile = a.role_tile[wave];
+    if (ci < 0) s3_first_role(a, geo, lds0, j0, rows, T, lane);
+    else {
+        switch (a.conv[ci].in.octs) {
+            case 1: s3_conv_role<1>(a, geo, ci, tile, lds0, j0, rows, T, lane); break;
+            case 2: s3_conv_role<2>(a, geo, ci, tile, lds0, j0, rows, T, lane); break;
+            case 3: s3_conv_role<3>(a, geo, ci, tile, lds0, j0, rows, T, lane); break;
+            default: s3_conv_role<4>(a, geo, ci, tile, lds0, j0, rows, T, lane); break;
+        }
+    }
+}
+
+}  // namespace dcscn

@@ -707,6 +707,59 @@ void densify_features(dcscn_ctx* h) {
     if (!used) h->bufs[cat].stride = 0;                         // the concat tensor no longer exists
 }
 
+// ---- row-streamed feature extractor of the non-separable narrow nets (feat3_stream.hpp) --------------------------------------
+// CNN1 .. CNNL of a net whose feature layers are plain 3x3 convs of at most 32 channels (the c-DCSCN checkpoints: 32 .. 8) become ONE
+// launch; runs behind densify_features (every layer stores into its own dense tensor, the 1x1 GEMM A1 || B1 reads them as before).
+// The layers' own launches stay in Op::fused: the float32 plan of a flagged image and split16 = 0 run those.
+void fuse_feat3_stream(dcscn_ctx* h) {
+    const dcscn_config& c = h->cfg;
+    const int L = c.layers;
+    if (!h->stream_dense || c.depthwise_separable || c.cnn_size != 3 || L < 2 || L > kS3MaxL || (int)h->ops.size() < L) return;
+    int waves = 1;
+    size_t lds = 0;
+    for (int i = 0; i < L; ++i) {
+        if (h->sched[i] > 32) return;
+        if (i > 0) waves += (h->sched[i] + 15) / 16;
+        if (i + 1 < L) lds += (size_t)3 * kStreamRowPx * (2 * ((h->sched[i] + 7) / 8) + 1) * 16;
+    }
+    if (waves > kS3MaxWaves || lds > 150 * 1024) return;
+    const Op& c1 = h->ops[0];
+    if (c1.kind != OP_CIN1 || c1.ks != 3 || c1.in_buf != EXT_X || c1.act != ACT_ALPHA || c1.out_off[0] != 0 || c1.out_buf[0] < 0 || c1.segs.size() != 1) return;
+    for (int i = 1; i < L; ++i) {
+        const Op& o = h->ops[i];
+        if (o.kind != OP_CONV || o.ks != 3 || o.dwk != 0 || o.ps != 1 || o.residual || o.act != ACT_ALPHA || o.segs.size() != 1 || o.tconv_s > 0 || o.fold_s > 0 ||
+            o.res != 1 || o.cin != h->sched[i - 1] || o.cout != h->sched[i] || o.in_buf != h->ops[i - 1].out_buf[0] || o.in_off != 0 || o.out_off[0] != 0 ||
+            o.out_buf[0] < 0 || o.split < (1 << 29) || !o.multi.empty())
+            return;
+        for (size_t k = 0; k < o.chan_map.size(); ++k)
+            if (o.chan_map[k] != (int)k) return;
+        // every layer's tensor must be its own (densify_features): nobody else may write it
+        for (int k = 0; k < i; ++k)
+            if (h->ops[k].out_buf[0] == o.out_buf[0]) return;
+    }
+    Op f;
+    f.kind = OP_STREAM3;
+    f.name = "CNN1.." + h->ops[L - 1].name + " (streamed)";
+    f.ks = 3;
+    f.cin = 1;
+    f.cout = h->sched[L - 1];
+    f.res = 1;
+    f.act = ACT_ALPHA;
+    f.in_buf = EXT_X;
+    f.out_buf[0] = f.out_buf[1] = h->ops[L - 1].out_buf[0];
+    f.out_width[0] = pad4(h->sched[L - 1]);
+    f.halo = L;
+    f.bytes = 4;
+    for (int i = 0; i < L; ++i) {
+        f.macs += h->ops[i].macs;
+        f.bytes += 4 * (int64_t)pad4(h->sched[i]);
+        f.fused.push_back(h->ops[i]);
+        f.extra_out.push_back(h->ops[i].out_buf[0]);
+    }
+    h->ops.erase(h->ops.begin(), h->ops.begin() + L);
+    h->ops.insert(h->ops.begin(), f);
+}
+
 // ---- P16 tensors (p16.hpp) ----------------------------------------------------------------------------
 // A workspace tensor is kept in the pre-split form when EVERY launch that writes it can store (hi | lo) units -- conv_cin1, conv3_h,
 // conv3_h8, conv_nin_h with a plain NHWC destination on a 16-channel boundary -- and EVERY launch that reads it is a split16 kernel
@@ -732,6 +785,7 @@ void plan_p16(dcscn_ctx* h) {
         return true;
     };
     auto can_write = [&](const Op& op, int k) {
+        if (op.kind == OP_STREAM3) return op.h16.on;             // (stores P16 units or float32, per tensor)
         if (op.kind == OP_CIN1) return k == 0 && op.out_off[0] == 0 && op.ks <= 3;   // (conv_cin1's octet-per-thread store path holds 2 x taps filter quads)
         if (op.kind != OP_CONV || !op.h16.on || op.fold_s > 0 || op.ps != 1 || op.residual || op.dwk != 0) return false;
         if (op.out_off[k] % 16 != 0) return false;
@@ -751,12 +805,15 @@ void plan_p16(dcscn_ctx* h) {
                 if (b < 0 || (k == 1 && op.split >= (1 << 29))) continue;
                 if (ok[b] && !can_write(op, k)) { ok[b] = 0; changed = true; }
             }
+            for (int b : op.extra_out)
+                if (ok[b] && !can_write(op, 0)) { ok[b] = 0; changed = true; }
         }
     }
     for (const Op& op : h->ops) {
         for (int b : inputs(op)) read[b] = 1;
         for (int k = 0; k < 2; ++k)
             if (op.out_buf[k] >= 0 && !(k == 1 && op.split >= (1 << 29))) written[op.out_buf[k]] = 1;
+        for (int b : op.extra_out) written[b] = 1;
     }
     h->any_p16 = false;
     h->p16_max_res = 1;
@@ -775,14 +832,17 @@ void plan_p16(dcscn_ctx* h) {
     // the float32 plan of a flagged image (exec.hip: run_forward): every launch downstream of a split16 launch or of a P16 tensor
     std::vector<char> dirty(nbuf, 0);
     for (Op& op : h->ops) {
-        bool r = (op.kind == OP_CONV || op.kind == OP_STREAM || op.kind == OP_TAIL) && op.h16.on;
+        bool r = (op.kind == OP_CONV || op.kind == OP_STREAM || op.kind == OP_TAIL || op.kind == OP_STREAM3) && op.h16.on;
         for (int b : inputs(op)) r = r || dirty[b];
         for (int k = 0; k < 2; ++k)
             if (op.out_buf[k] >= 0 && !(k == 1 && op.split >= (1 << 29))) r = r || h->bufs[op.out_buf[k]].p16_ok;
         op.h16.rerun = r;
-        if (r)
+        for (int b : op.extra_out) r = r || h->bufs[b].p16_ok;
+        if (r) {
             for (int k = 0; k < 2; ++k)
                 if (op.out_buf[k] >= 0) dirty[op.out_buf[k]] = 1;
+            for (int b : op.extra_out) dirty[b] = 1;
+        }
     }
 }
 

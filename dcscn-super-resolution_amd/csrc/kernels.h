@@ -234,6 +234,40 @@ hipError_t tail_launch(const TailArgs& a, int grid, bool f16, hipStream_t stream
 void stream_init_kernels();
 hipError_t stream_launch(const StreamArgs& a, int grid, bool f16, hipStream_t stream);
 
+// ---- row-streamed feature extractor of the NON-separable narrow nets (feat3_stream.hpp) ----
+constexpr int kS3MaxL = 8;         // feature layers
+constexpr int kS3MaxWaves = 10;    // 1 (CNN1) + one per (conv, 16-channel output tile)
+struct S3Ring { int32_t off, px, octs; };              // LDS byte offset of [3 slots][kStreamRowPx][px bytes] P16 units; px = (2 octs + 1) * 16 (0: no ring)
+struct S3Out {                     // a layer's global tensor: P16 (p16.base != nullptr) or float32 NHWC
+    P16Desc p16;
+    float* ptr;
+    int32_t stride, width;         // floats per pixel, stored channels (multiple of 4)
+};
+struct S3Conv {
+    S3Ring in, out;
+    int32_t lag;                   // computes stream row t - lag at step t
+    int32_t w_off;                 // blob offset (floats) of the filter fragments [step][tile][hi | lo][64 lanes][8 halfs], scaled by 2^e
+    int32_t ba_off;                // blob offset of bias * 2^e [32], slope - 1 [32]
+    int32_t tiles;                 // 16-channel output tiles
+    float inv;                     // 2^-e
+};
+struct Stream3Args {
+    const float* x;                // [N, H, W] luma
+    const float* blob;             // packed parameters (pack.hip: pack_feat3_stream)
+    int32_t N, H, W;
+    int32_t n_strips, useful_w, halo, n_blocks, useful_h, rows_c, n_jobs, jobs_per_wg;      // as StreamArgs
+    int32_t L, total_lag, n_waves;
+    int8_t role_conv[kS3MaxWaves]; // wave -> -1: CNN1, else conv index (0 = CNN2)
+    int8_t role_tile[kS3MaxWaves]; // ... and its output tile
+    int32_t first_w;               // blob offset of CNN1: filter [9][32], bias [32], slope - 1 [32]
+    S3Ring first_out;
+    S3Conv conv[kS3MaxL];
+    S3Out out[kS3MaxL];            // out[0] = CNN1's tensor, out[i + 1] = conv i's
+    int32_t ring_bytes;
+    int32_t* redo;                 // [0] pass flag, [1 + image] (split16.hpp)
+};
+hipError_t stream3_launch(const Stream3Args& a, int grid, hipStream_t stream);
+
 // widest channel tile (in units of 16) the fused-depthwise pointwise kernels are instantiated for
 int conv_max_fused_dw_nt();
 

@@ -17,6 +17,7 @@ int upload(dcscn_ctx* h, const void* host, size_t bytes, void** dev) {
 
 
 int finalize_op(dcscn_ctx* h, Op& op) {
+    if (op.kind == OP_STREAM3) return pack_feat3_stream(h, op);
     if (op.kind == OP_STREAM) return pack_feat_stream(h, op);
     if (op.kind == OP_TAIL) return pack_tail_stream(h, op);
     if (op.kind == OP_DW) {
@@ -733,6 +734,117 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
         a.nin_inv = std::ldexp(1.0f, -e);
     }
     rc = upload(h, blob16.data(), blob16.size() * sizeof(float), &op.h16.d_w);
+    op.h16.on = rc == DCSCN_OK;
+    return rc;
+}
+
+// ---- feat3_stream (feat3_stream.hpp): rings, role table and filter fragments of the fused CNN1 .. CNNL launch ---------------------
+int pack_feat3_stream(dcscn_ctx* h, Op& op) {
+    const int L = (int)op.fused.size();
+    for (Op& sub : op.fused) {                      // the layers' own launches: the float32 plan of a flagged image, and split16 = 0
+        const int rc = finalize_op(h, sub);
+        if (rc) return rc;
+    }
+    Stream3Args& a = op.stream3;
+    a = Stream3Args{};
+    a.L = L;
+    a.total_lag = 2 * (L - 1);
+    auto tens = [&](int id) -> const std::vector<float>& { return h->tensors[id].data; };
+    int lds = 0;
+    std::vector<S3Ring> ring(L);
+    for (int i = 0; i < L; ++i) {
+        const int octs = (h->sched[i] + 7) / 8;
+        ring[i] = S3Ring{lds, i + 1 < L ? (2 * octs + 1) * 16 : 0, octs};
+        if (i + 1 < L) lds += 3 * kStreamRowPx * ring[i].px;
+    }
+    a.ring_bytes = lds;
+    if (lds > 160 * 1024) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream needs %d bytes of LDS", lds);
+    a.first_out = ring[0];
+    std::vector<float> blob;
+    {   // CNN1: filter [9][32] (tap major), bias [32], slope - 1 [32]
+        const Op& c1 = op.fused[0];
+        const ColSeg& sg = c1.segs[0];
+        const int C = h->sched[0];
+        a.first_w = 0;
+        blob.resize(288 + 64, 0.0f);
+        const std::vector<float>& w = tens(sg.w);              // [3, 3, 1, C]
+        for (int t = 0; t < 9; ++t)
+            for (int co = 0; co < C; ++co) blob[(size_t)t * 32 + co] = w[(size_t)t * C + sg.col0 + co];
+        for (int co = 0; co < C; ++co) {
+            blob[288 + co] = sg.b >= 0 ? tens(sg.b)[sg.col0 + co] : 0.0f;
+            blob[320 + co] = (sg.alpha >= 0 ? tens(sg.alpha)[sg.col0 + co] : c1.const_alpha) - 1.0f;
+        }
+    }
+    int waves = 0;
+    std::vector<int> cost;                          // MFMAs per row of each wave
+    a.role_conv[waves] = -1; a.role_tile[waves] = 0; cost.push_back(0); ++waves;
+    for (int i = 1; i < L; ++i) {
+        const Op& o = op.fused[i];
+        const ColSeg& sg = o.segs[0];
+        const int cin = h->sched[i - 1], cout = h->sched[i];
+        const int octs = ring[i - 1].octs, steps = (9 * octs + 3) / 4, tiles = (cout + 15) / 16;
+        S3Conv& cv = a.conv[i - 1];
+        cv.in = ring[i - 1];
+        cv.out = ring[i];
+        cv.lag = 2 * i;
+        cv.tiles = tiles;
+        const std::vector<float>& w = tens(sg.w);              // [3, 3, cin, cout_total]
+        const int wcols = (int)h->tensors[sg.w].shape.back();
+        std::vector<float> all((size_t)9 * cin * cout);
+        for (int t = 0; t < 9; ++t)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int co = 0; co < cout; ++co) all[((size_t)t * cin + ci) * cout + co] = w[((size_t)t * cin + ci) * wcols + sg.col0 + co];
+        const int e = split16_scale_exp(all.data(), all.size());
+        cv.inv = std::ldexp(1.0f, -e);
+        cv.w_off = (int)blob.size();
+        blob.resize(blob.size() + (size_t)steps * tiles * 2 * 64 * 4, 0.0f);
+        uint16_t* d16 = reinterpret_cast<uint16_t*>(&blob[cv.w_off]);
+        for (int s = 0; s < steps; ++s)
+            for (int n = 0; n < tiles; ++n)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int q = lane >> 4, co = 16 * n + (lane & 15);
+                    const int p = 4 * s + q, tap = p / octs, oct = p - tap * octs;
+                    uint16_t* hi = d16 + ((size_t)((s * tiles + n) * 2 + 0) * 64 + lane) * 8;
+                    uint16_t* lo = d16 + ((size_t)((s * tiles + n) * 2 + 1) * 64 + lane) * 8;
+                    for (int t8 = 0; t8 < 8; ++t8) {
+                        const int ci = 8 * oct + t8;
+                        const float wv = tap < 9 && ci < cin && co < cout ? all[((size_t)tap * cin + ci) * cout + co] : 0.0f;
+                        split16_host(std::ldexp(wv, e), &hi[t8], &lo[t8]);
+                    }
+                }
+        cv.ba_off = (int)blob.size();
+        blob.resize(blob.size() + 64, 0.0f);
+        for (int co = 0; co < cout; ++co) {
+            blob[cv.ba_off + co] = std::ldexp(sg.b >= 0 ? tens(sg.b)[sg.col0 + co] : 0.0f, e);
+            blob[cv.ba_off + 32 + co] = (sg.alpha >= 0 ? tens(sg.alpha)[sg.col0 + co] : o.const_alpha) - 1.0f;
+        }
+        for (int n = 0; n < tiles; ++n) {
+            if (waves >= kS3MaxWaves) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream needs more than %d waves", kS3MaxWaves);
+            a.role_conv[waves] = (int8_t)(i - 1); a.role_tile[waves] = (int8_t)n; cost.push_back(9 * steps); ++waves;
+        }
+    }
+    a.n_waves = waves;
+    {   // wave w runs on SIMD w & 3: deal the roles, heaviest first, onto the least loaded SIMD that has a wave slot left
+        std::vector<int> order(waves);
+        for (int i = 0; i < waves; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return cost[x] > cost[y]; });
+        int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+        int8_t rc[kS3MaxWaves], rt[kS3MaxWaves];
+        for (int w = 0; w < kS3MaxWaves; ++w) { rc[w] = -1; rt[w] = 0; }
+        for (int idx : order) {
+            int pick = -1;
+            for (int sd = 0; sd < 4; ++sd) {
+                const int cap = (waves - sd + 3) / 4;
+                if (used[sd] < cap && (pick < 0 || load[sd] < load[pick])) pick = sd;
+            }
+            const int w = pick + 4 * used[pick];
+            rc[w] = a.role_conv[idx]; rt[w] = a.role_tile[idx];
+            used[pick] += 1;
+            load[pick] += cost[idx] + 20;
+        }
+        for (int w = 0; w < kS3MaxWaves; ++w) { a.role_conv[w] = rc[w]; a.role_tile[w] = rt[w]; }
+    }
+    const int rc = upload(h, blob.data(), blob.size() * sizeof(float), (void**)&op.d_w);
     op.h16.on = rc == DCSCN_OK;
     return rc;
 }

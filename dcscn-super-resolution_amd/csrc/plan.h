@@ -27,7 +27,7 @@ inline int pad4(int c) { return (c + 3) & ~3; }
 inline int pad16(int c) { return (c + 15) & ~15; }
 
 enum { EXT_X = -1, EXT_X2 = -2, EXT_Y = -3 };
-enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2, OP_COUT1 = 3, OP_STREAM = 4, OP_TAIL = 5 };
+enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2, OP_COUT1 = 3, OP_STREAM = 4, OP_TAIL = 5, OP_STREAM3 = 6 };
 
 struct TensorSpec {
     std::string name;
@@ -104,6 +104,9 @@ struct Op {
     std::vector<Op> fused;
     StreamArgs stream{};
     TailArgs tail{};
+    Stream3Args stream3{};                    // OP_STREAM3 (fuse_feat3_stream): CNN1 .. CNNL of a non-separable narrow net as one launch; `fused` = the
+                                              // layers' own launches: the float32 plan of a flagged image and the split16 = 0 path run those
+    std::vector<int> extra_out;               // OP_STREAM3: the workspace tensors it writes (one per layer)
     int halo = -1;                            // >= 0: receptive-field radius of the op in ITS pixels (else ks / 2)
     // split16 variant of the launch (split16.hpp: the contraction on the f16 matrix pipe at f32 accuracy), taken when the handle's
     // "split16" option is on; the f32 launch then runs behind it as the fallback of the units it flags
@@ -196,6 +199,7 @@ struct dcscn_ctx {
     hipGraphExec_t graph_exec = nullptr;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
     bool stream_tail = true;                 // the x4 tail of the same nets as one launch (fuse_tail_stream)
+    bool stream_dense = true;                // non-separable narrow nets: CNN1 .. CNNL as one row-streamed launch (fuse_feat3_stream; option "stream_dense")
     bool stream_features = true;             // separable narrow nets: CNN1 .. B2 as one row-streamed launch (fuse_feat_stream)
     int split16_mask = 3;                    // debugging aid (option "split16" 2 / 3): bit 0 = conv3_h, bit 1 = conv_nin_h
     bool split16 = true;                     // eligible contractions on the f16 matrix pipe (conv3_h, conv_nin_h); option "split16" 0 = pure f32 kernels
@@ -251,6 +255,7 @@ int stream_chunk_channel(int quads, int ch, int q, int s);
 bool stream_conv_supported(int in_quads, int out_tiles);
 void fuse_feat_stream(dcscn_ctx* h);
 void fuse_tail_stream(dcscn_ctx* h);
+void fuse_feat3_stream(dcscn_ctx* h);
 void densify_features(dcscn_ctx* h);
 void plan_p16(dcscn_ctx* h);
 inline bool p16_active(const dcscn_ctx* h) { return h->p16 && h->any_p16 && h->split16 && h->split16_mask == 3; }
@@ -259,6 +264,7 @@ int upload(dcscn_ctx* h, const void* host, size_t bytes, void** dev);
 int finalize_op(dcscn_ctx* h, Op& op);
 int pack_feat_stream(dcscn_ctx* h, Op& op);
 int pack_tail_stream(dcscn_ctx* h, Op& op);
+int pack_feat3_stream(dcscn_ctx* h, Op& op);
 // exec.hip
 int ensure_workspace(dcscn_ctx* h, int nb, int H, int W, hipStream_t stream);
 // redo = false: the launch of the pass (split16 kernels where the handle's options allow); true: the op's float32 launch gated by the

@@ -173,6 +173,10 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * with every intermediate tensor in LDS, and -- x4 models with a 32-channel pixel shuffler -- Up-PS, Up-PS2, the last
  * reconstruction conv and the residual add as a second one.  0 = the layer-by-layer launches (same function, f32 results
  * differ by accumulation order only).
+ * "stream_dense" (default 1; before dcscn_finalize only): the NON-separable narrow nets (plain 3x3 feature layers of <= 32 filters --
+ * the c-DCSCN checkpoints) run CNN1 .. CNNL as one row-streamed launch on the f16 matrix pipe (csrc/feat3_stream.hpp: three-row rings of
+ * pre-split units in LDS, filter fragments in registers, every layer's rows written once for A1 || B1); with split16 = 0, and for a
+ * flagged image, the layers run one by one.  0 = always layer by layer.
  * "split16" (default 1; any time): the 3x3 convs the Winograd kernel would take and the wide 1x1 convs run their contraction
  * on the f16 matrix pipe at f32 accuracy -- every f32 operand as an f16 (hi, lo) pair, three products per MAC, f32
  * accumulation; measured error at the f32 kernels' level (profiles/r03_f16x3_numerics.txt).  Weights are scaled

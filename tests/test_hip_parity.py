@@ -139,7 +139,8 @@ def test_split16_option_both_ways(oracle, name, split16):
         eng.load_weights(weights)
         eng.set_option("split16", 1 if split16 else 0)
         kernels = {o["kernel"] for o in eng.ops()}
-        assert ("conv3_h" in kernels) == split16 and ("conv_wino2" in kernels) == (not split16), kernels
+        # (the non-separable narrow net runs CNN1 .. CNNL as one streamed launch on the split16 path, layer by layer otherwise)
+        assert ("conv3_h" in kernels or "feat3_stream" in kernels) == split16 and ("conv_wino2" in kernels or "layer by layer" in kernels) == (not split16), kernels
         y = eng.forward(x, x2)
         eng.set_option("split16", 0 if split16 else 1)      # and back the other way on the same handle
         y2 = eng.forward(x, x2)
@@ -684,6 +685,7 @@ def test_dense_feature_buffers_are_bit_identical_to_the_concat_tensor(oracle, na
     for dense in (1, 0):
         with engine.Engine(cfg, device=0) as eng:
             eng.set_option("dense_features", dense)
+            eng.set_option("stream_dense", 0)                 # (the streamed CNN1 .. CNNL launch of the narrow nets exists on dense buffers only)
             eng.load_weights(weights)
             outs.append(eng.forward(x, x2))
     assert outs[0].tobytes() == outs[1].tobytes()
@@ -835,3 +837,28 @@ def test_p16_overflow_recomputes_the_image_on_the_float32_plan(oracle):
     assert np.array_equal(y[0], clean[0]) and np.array_equal(y[2], clean[2])
     assert np.array_equal(y[1], y32[1])
     assert np.array_equal(again, clean)
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4])
+def test_streamed_dense_feature_extractor(oracle, scale):
+    """feat3_stream: CNN1 .. CNNL of the non-separable narrow nets (the c-DCSCN checkpoints' topology) as one row-streamed launch on the
+    f16 matrix pipe -- taken by default (kernel list), within the bars of the float64 oracle on patches, on an image wider than a strip
+    (column strips) and on a tall one (row blocks), and consistent with the layer-by-layer launches (option stream_dense = 0)."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS["L7_F32to8_x%d" % scale])
+    weights = oracle.synthetic_weights(cfg, seed=21)
+    for n, h, w in ((3, 48, 48), (1, 37, 131), (1, 300, 20)):
+        x, x2 = synthetic_batch(n, h, w, scale, seed=22)
+        ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+        with engine.Engine(cfg, device=0) as eng:
+            eng.load_weights(weights)
+            assert "feat3_stream" in [o["kernel"] for o in eng.ops()], eng.ops()
+            y = eng.forward(x, x2)
+        with engine.Engine(cfg, device=0) as eng:
+            eng.set_option("stream_dense", 0)
+            eng.load_weights(weights)
+            assert "feat3_stream" not in [o["kernel"] for o in eng.ops()]
+            y0 = eng.forward(x, x2)
+        err, err0 = float(np.max(np.abs(y - ref))), float(np.max(np.abs(y0 - ref)))
+        print("x%d %dx%dx%d: streamed max-abs %.3g, layer by layer %.3g" % (scale, n, h, w, err, err0))
+        assert np.isfinite(y).all() and err <= MAX_ABS_TOL and err0 <= MAX_ABS_TOL
