@@ -3,7 +3,8 @@
 //
 // Layer by layer these nets are bound by HBM round trips and launch overheads (seven launches of 0.08 - 0.21 ms for ~0.1 ms of matrix
 // work); here a workgroup owns a 48-pixel column strip and walks down its rows like feat_stream.hpp (same jobs, strips, row blocks,
-// separator rows, two barriers per step), every layer keeps a three-row ring of its output in LDS, and every layer's rows also go to
+// separator rows), every layer keeps a four-slot row ring of its output in LDS (three rows are read while the fourth is written: one barrier
+// per step), and every layer's rows also go to
 // global memory ONCE, for the 1x1 GEMM A1 || B1 that follows (as P16 tensors or float32, whatever plan_p16 gave the tensor).
 //
 //   * rings hold P16 units (p16.hpp): per pixel and channel octet [hi 8 halfs | lo 8 halfs], written by the producing wave's epilogue
@@ -11,8 +12,8 @@
 //   * a conv is a K = 9 * Cin implicit GEMM on v_mfma_f32_16x16x32_f16 with the (tap, octet) pairs packed four to an instruction (conv3_h's
 //     packed tail, for every chunk): lane group q of step s multiplies pair 4 s + q; ceil(9 * octets / 4) = 3 / 5 / 7 / 9 steps.
 //     Three products per accumulator (split16.hpp), filters f16 (hi, lo) scaled by 2^e, bias * 2^e as the first C operand.
-//   * a wave = (conv, 16-channel output tile); its filter fragments -- at most 9 steps x (hi, lo) = 72 registers -- live in REGISTERS for the
-//     whole launch (the dense filters of the net are 140 KB as fragments: they do not fit beside the rings, and nothing else needs them).
+//   * a wave = a conv (one or two 16-channel output tiles); its filter fragments -- at most 9 steps x 2 tiles x (hi, lo) = 144 registers of the
+//     256 an 8-wave workgroup leaves each wave -- live in REGISTERS for the whole launch (the dense filters of the net are 140 KB as fragments: they do not fit beside the rings, and nothing else needs them).
 //     Pixel tile m of lane column j is pixel 3 j + m, as in feat_stream.
 //   * wave -> SIMD placement balances the MFMA counts (pack.hip: pack_feat3_stream); CNN1 (one input channel) is VALU work on its own wave.
 //
@@ -20,6 +21,11 @@
 #pragma once
 #include "feat_stream.hpp"
 #include "p16.hpp"
+
+#ifndef S3_ABL
+#define S3_ABL 0           // tools/s3_abl.sh: timing-only builds (results wrong by design): 1 no MFMAs, 2 no ring reads, 4 no global stores, 8 no CNN1 arithmetic,
+                           // 16 no epilogue arithmetic (PReLU / split / swap)
+#endif
 
 namespace dcscn {
 
@@ -31,16 +37,30 @@ __device__ __forceinline__ StreamArgs s3_geometry(const Stream3Args& a) {
     return g;
 }
 
-// one unit per lane (tile `tile`, lane group q: octet 2 tile + (q >> 1), part q & 1) of pixel (img, r, cx) -> the layer's global tensor
-__device__ __forceinline__ void s3_store_global(const S3Out& o, long long pix, int tile, int q, const u32x4 unit, const f32x4 v) {
-    if (o.p16.base) {
-        const int octet = 2 * tile + (q >> 1);
-        if (octet < o.p16.octs) {
-            const int chunk = octet >> 2, rec = p16_rec_bytes(o.p16.octs, chunk);
-            *reinterpret_cast<u32x4*>(o.p16.base + (long long)chunk * o.p16.plane + 128 + pix * rec + (octet & 3) * 32 + (q & 1) * 16) = unit;
-        }
-    } else if (16 * tile + 4 * q < o.width) {
-        *reinterpret_cast<f32x4*>(o.ptr + pix * o.stride + 16 * tile + 4 * q) = v;
+// A layer's row in its global tensor.  At most 32 channels = one P16 chunk, so the record size is wave uniform: `base` = the record of the
+// strip's column 0 in this image row (one scalar 64-bit computation per row), a lane adds (3 j + m) * rec + its unit's 16 n' bytes -- no
+// per-store address arithmetic (r05's first build spent ~1.5 k of 6.6 k cycles per step on 64-bit multiplies in front of its stores).
+struct S3RowOut {
+    char* base;        // P16: record of (img, r, sx); float32: &ptr[pixel (img, r, sx)][0]
+    unsigned rec;      // bytes per pixel
+    bool p16;
+};
+__device__ __forceinline__ S3RowOut s3_row_out(const S3Out& o, const StreamRow& ri, int H, int W) {
+    const long long pix = ((long long)ri.img * H + ri.r) * W + ri.sx;
+    S3RowOut r;
+    r.p16 = o.p16.base != nullptr;
+    r.rec = r.p16 ? (unsigned)p16_rec_bytes(o.p16.octs, 0) : (unsigned)o.stride * 4u;
+    r.base = r.p16 ? o.p16.base + 128 + pix * (long long)r.rec : reinterpret_cast<char*>(o.ptr) + pix * (long long)r.rec;
+    return r;
+}
+// tile n, lane group q: P16 unit 4 n + q of the record (octet 2 n + (q >> 1), part q & 1); float32: channels 16 n + 4 q ..
+__device__ __forceinline__ void s3_store_global(const S3Out& o, const S3RowOut& ro, int col, int n, int q, const u32x4 unit, const f32x4 v) {
+    if constexpr ((S3_ABL & 4) != 0) return;
+    const unsigned off = (unsigned)col * ro.rec + (unsigned)(n * 64 + q * 16);
+    if (ro.p16) {
+        if (2 * n + (q >> 1) < o.p16.octs) *reinterpret_cast<u32x4*>(ro.base + off) = unit;
+    } else if (16 * n + 4 * q < o.width) {
+        *reinterpret_cast<f32x4*>(ro.base + off) = v;
     }
 }
 
@@ -58,7 +78,9 @@ __device__ __forceinline__ void s3_first_role(const Stream3Args& a, const Stream
     const float m1 = opaque_minus_one();
     const h2 zero2 = p16_opaque_zero2();
     const unsigned out_px = (unsigned)a.first_out.px, out_row = (unsigned)kStreamRowPx * out_px;
-    float xw[4][5];
+    // rows g-1 .. g+3 of the input in a rotating five-row window (slot = row mod 5, compile-time: the step loop is unrolled by five): the
+    // row loaded at step t is first used at step t + 2 -- with one step of distance (r05's first build) every step waited for a global load
+    float xw[5][5];
     StreamCursor lc, cc;
     auto load_row = [&](int gs, float (&dst)[5]) DCSCN_INL {
         const bool in = gs >= 0 && gs < rows;
@@ -72,21 +94,23 @@ __device__ __forceinline__ void s3_first_role(const Stream3Args& a, const Stream
         }
     };
 #pragma unroll
-    for (int k = 0; k < 5; ++k) xw[1][k] = 0.0f;
-    load_row(0, xw[2]);
-    load_row(1, xw[3]);
-    for (int t = 0; t < T; ++t) {
+    for (int k = 0; k < 5; ++k) xw[4][k] = 0.0f;              // row -1
+    load_row(0, xw[0]);
+    load_row(1, xw[1]);
+    load_row(2, xw[2]);
+#ifdef S3_DBG
+    long long dbg_c = 0, dbg_b = 0, dbg_t = __builtin_readcyclecounter();
+#endif
+    auto step = [&](auto p_, int t) DCSCN_INL {
+        constexpr int p = decltype(p_)::value;                // t mod 5
         const int g = t;
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int k = 0; k < 5; ++k) xw[s][k] = xw[s + 1][k];
-        load_row(g + 2, xw[3]);
+        load_row(g + 3, xw[(p + 3) % 5]);
         const bool live = g < rows;
-        u32x4 unit[kStreamMT][2];
         if (live) {
             const StreamRow ri = stream_row(geo, j0, cc, g);
+            const S3RowOut ro = s3_row_out(a.out[0], ri, a.H, a.W);
             float chk = 0.0f;
+            const unsigned wb = lds0 + a.first_out.off + (unsigned)(g & 3) * out_row + (unsigned)(3 * j + 1) * out_px + (unsigned)q * 16u;
 #pragma unroll
             for (int m = 0; m < kStreamMT; ++m) {
                 const int cx = ri.sx + 3 * j + m;
@@ -97,49 +121,69 @@ __device__ __forceinline__ void s3_first_role(const Stream3Args& a, const Stream
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) s += w9[n][dy * 3 + dx] * xw[dy][m + dx];
+                        for (int dx = 0; dx < 3; ++dx) if (!(S3_ABL & 8) || (dy == 1 && dx == 1)) s += w9[n][dy * 3 + dx] * xw[(p + 4 + dy) % 5][m + dx];
                     f32x4 v = stream_prelu(bs[n] + s, al[n]);
                     v = ok ? v : kStreamZero;
-                    unit[m][n] = p16_unit(v, m1, chk, zero2);
-                    if (ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(a.out[0], ((long long)ri.img * a.H + ri.r) * a.W + cx, n, q, unit[m][n], v);
+                    const u32x4 unit = p16_unit(v, m1, chk, zero2);
+                    if (ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(a.out[0], ro, 3 * j + m, n, q, unit, v);
+                    // (four ring slots: row g goes to its slot while CNN2 reads rows g-3 .. g-1; ONE barrier per step)
+                    if (2 * n + (q >> 1) < a.first_out.octs) stream_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, __builtin_bit_cast(f32x4, unit));
                 }
             }
             if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
         }
+#ifdef S3_DBG
+        const long long tb = __builtin_readcyclecounter();
+        dbg_c += tb - dbg_t;
+#endif
         stream_barrier();
-        if (live) {
-            const unsigned wb = lds0 + a.first_out.off + (unsigned)(g % 3) * out_row + (unsigned)(3 * j + 1) * out_px + (unsigned)q * 16u;
-#pragma unroll
-            for (int m = 0; m < kStreamMT; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    if (2 * n + (q >> 1) < a.first_out.octs) stream_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, __builtin_bit_cast(f32x4, unit[m][n]));
-        }
-        stream_barrier();
+#ifdef S3_DBG
+        dbg_t = __builtin_readcyclecounter();
+        dbg_b += dbg_t - tb;
+#endif
+    };
+    for (int t = 0; t < T; t += 5) {
+        step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < T) step(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < T) step(std::integral_constant<int, 2>{}, t + 2);
+        if (t + 3 < T) step(std::integral_constant<int, 3>{}, t + 3);
+        if (t + 4 < T) step(std::integral_constant<int, 4>{}, t + 4);
     }
+#ifdef S3_DBG
+    if (a.dbg && blockIdx.x == 0 && lane == 0) { long long* d = a.dbg + (threadIdx.x >> 6) * 4; d[0] = dbg_c; d[1] = dbg_b; d[2] = T; }
+#endif
 }
 
-// ---- CNN2 .. CNNL: one 16-channel output tile of a 3x3 conv from the predecessor's ring --------------------------------
-// OCTS = channel octets of the input ring (compile time: the step count, every LDS offset an immediate or one register per step)
-template <int OCTS>
-__device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamArgs& geo, int ci, int tile, unsigned lds0, int j0, int rows, int T, int lane) {
+// ---- CNN2 .. CNNL: a 3x3 conv (NT 16-channel output tiles) from the predecessor's ring ---------------------------------
+// OCTS = channel octets of the input ring (compile time: the step count, every LDS offset an immediate or one register per step).
+// One wave per conv: the B operands of a step are read ONCE for all its output tiles -- the kernel is bound by LDS read bandwidth (a
+// ds_read_b128 is 1 KB: ~250 of them per row step and workgroup), not by the MFMAs; the first build (one wave per output tile) read
+// them twice.
+template <int OCTS, int NT>
+__device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamArgs& geo, int ci, unsigned lds0, int j0, int rows, int T, int lane) {
     const S3Conv& c = a.conv[ci];
     const S3Out& og = a.out[ci + 1];
     constexpr int STEPS = (9 * OCTS + 3) / 4;
     constexpr unsigned IN_PX = (unsigned)(2 * OCTS + 1) * 16u, IN_ROW = (unsigned)kStreamRowPx * IN_PX;
     const int j = lane & 15, q = lane >> 4;
     // filter fragments of this wave's tile: [step][tile][hi | lo][64 lanes][8 halfs] in the blob
-    h8 fh[STEPS], fl[STEPS];
+    h8 fh[STEPS][NT], fl[STEPS][NT];
+    f32x4 bs[NT], am1[NT];
     {
         const char* wsrc = reinterpret_cast<const char*>(a.blob + c.w_off);
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            fh[s] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((s * c.tiles + tile) * 2 + 0) * 64 + lane) * 16);
-            fl[s] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((s * c.tiles + tile) * 2 + 1) * 64 + lane) * 16);
+        for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                fh[s][n] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((s * NT + n) * 2 + 0) * 64 + lane) * 16);
+                fl[s][n] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((s * NT + n) * 2 + 1) * 64 + lane) * 16);
+            }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            bs[n] = *reinterpret_cast<const f32x4*>(a.blob + c.ba_off + n * 16 + 4 * q);           // bias * 2^e
+            am1[n] = *reinterpret_cast<const f32x4*>(a.blob + c.ba_off + 32 + n * 16 + 4 * q);     // slope - 1
         }
     }
-    const f32x4 bs = *reinterpret_cast<const f32x4*>(a.blob + c.ba_off + tile * 16 + 4 * q);          // bias * 2^e
-    const f32x4 am1 = *reinterpret_cast<const f32x4*>(a.blob + c.ba_off + 32 + tile * 16 + 4 * q);    // slope - 1
     // step s, lane group q: pair p = 4 s + q = (tap, octet) with tap = p / OCTS.  For OCTS >= 2 the four lane groups of a step see at most two
     // taps -- tap0 = 4 s / OCTS below the lane-group threshold `thr`, tap0 + 1 from it on -- so row, column and octet offset are compile-time
     // constants selected by one compare; pairs past the last (tap 9) read valid units of tap 8 against zero filters.  OCTS = 1: four taps per
@@ -160,10 +204,16 @@ __device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamA
     const h2 zero2 = p16_opaque_zero2();
     const unsigned out_px = (unsigned)c.out.px, out_row = (unsigned)kStreamRowPx * out_px;
     StreamCursor cur;
+#ifdef S3_DBG
+    long long dbg_c = 0, dbg_b = 0, dbg_t = __builtin_readcyclecounter();
+#endif
+    // (Issuing the epilogue of row g - 1 between the MFMA groups of row g -- a software pipeline with the layers' lags spaced by three -- was
+    // built and measured in r05: 0.83 ms against 0.66, the heaviest wave 7.8 k cycles per step instead of 6.0 k: the ring stores and the B-operand
+    // reads share one in-order LGKM counter, and the waits for the one also wait for the other.)
     for (int t = 0; t < T; ++t) {
         const int g = t - c.lag;
         const bool live = g >= 0 && g < rows;
-        u32x4 unit[kStreamMT];
+        u32x4 unit[kStreamMT][NT];
         bool zero_row = true;
         if (live) {
             const StreamRow ri = stream_row(geo, j0, cur, g);
@@ -171,8 +221,8 @@ __device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamA
             if (!ri.zero) {
                 unsigned rb[3];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy) rb[dy] = lds0 + c.in.off + (unsigned)((g + 5 + dy) % 3) * IN_ROW + (unsigned)(3 * j) * IN_PX;   // rows g-1, g, g+1
-                f32x4 acc[kStreamMT];
+                for (int dy = 0; dy < 3; ++dy) rb[dy] = lds0 + c.in.off + (unsigned)((g + 3 + dy) & 3) * IN_ROW + (unsigned)(3 * j) * IN_PX;   // rows g-1, g, g+1
+                f32x4 acc[kStreamMT][NT];
                 static_for<0, STEPS>([&](auto s_) DCSCN_INL {
                     constexpr int s = decltype(s_)::value;
                     unsigned base;
@@ -190,40 +240,71 @@ __device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamA
                     h8 xh[kStreamMT], xl[kStreamMT];
 #pragma unroll
                     for (int m = 0; m < kStreamMT; ++m) {
+                        if constexpr ((S3_ABL & 2) != 0) { u32x4 z = {0x3c003c00u, 0x3c003c00u, base, 0x3c003c00u}; asm volatile("" : "+v"(z)); xh[m] = xl[m] = __builtin_bit_cast(h8, z); } else {
                         xh[m] = __builtin_bit_cast(h8, stream_ld(base + (unsigned)m * IN_PX));
                         xl[m] = __builtin_bit_cast(h8, stream_ld(base + (unsigned)m * IN_PX + 16u));
+                        }
                     }
+                    if constexpr ((S3_ABL & 1) != 0) {
 #pragma unroll
-                    for (int m = 0; m < kStreamMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s], xh[m], s == 0 ? bs : acc[m], 0, 0, 0);
+                        for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int m = 0; m < kStreamMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xl[m], acc[m], 0, 0, 0);
+                            for (int m = 0; m < kStreamMT; ++m) { if (s == 0) acc[m][n] = bs[n]; f32x4 tt = acc[m][n]; const h8 fa = fh[s][n], fb = fl[s][n], xa = xh[m], xb = xl[m]; asm volatile("" : "+v"(tt) : "v"(xa), "v"(xb), "v"(fa), "v"(fb)); acc[m][n] = tt; }
+                    } else
 #pragma unroll
-                    for (int m = 0; m < kStreamMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s], xh[m], acc[m], 0, 0, 0);
+                    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                        for (int m = 0; m < kStreamMT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s][n], xh[m], s == 0 ? bs[n] : acc[m][n], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < kStreamMT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s][n], xl[m], acc[m][n], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < kStreamMT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s][n], xh[m], acc[m][n], 0, 0, 0);
+                    }
                 });
                 float chk = 0.0f;
+                const S3RowOut ro = s3_row_out(og, ri, a.H, a.W);
 #pragma unroll
                 for (int m = 0; m < kStreamMT; ++m) {
                     const int cx = ri.sx + 3 * j + m;
-                    f32x4 v = stream_prelu(acc[m] * c.inv, am1);
-                    v = cx >= 0 && cx < a.W ? v : kStreamZero;      // SAME padding: columns outside the image are zero in every ring
-                    unit[m] = p16_unit(v, m1, chk, zero2);
-                    if (ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(og, ((long long)ri.img * a.H + ri.r) * a.W + cx, tile, q, unit[m], v);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        f32x4 v = (S3_ABL & 16) ? acc[m][n] : stream_prelu(acc[m][n] * c.inv, am1[n]);
+                        v = cx >= 0 && cx < a.W ? v : kStreamZero;      // SAME padding: columns outside the image are zero in every ring
+                        if constexpr ((S3_ABL & 16) != 0) unit[m][n] = __builtin_bit_cast(u32x4, v); else
+                        unit[m][n] = p16_unit(v, m1, chk, zero2);
+                        if (ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(og, ro, 3 * j + m, n, q, unit[m][n], v);
+                    }
                 }
                 if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
             }
         }
-        stream_barrier();
-        if (live && c.out.px > 0 && 2 * tile + (q >> 1) < c.out.octs) {
-            const unsigned wb = lds0 + c.out.off + (unsigned)(g % 3) * out_row + (unsigned)(3 * j + 1) * out_px + (unsigned)tile * 64u + (unsigned)q * 16u;
+        // four ring slots: row g goes to its slot while the next layer reads rows g-3 .. g-1 -- ONE barrier per step
+        if (live && c.out.px > 0) {
+            const unsigned wb = lds0 + c.out.off + (unsigned)(g & 3) * out_row + (unsigned)(3 * j + 1) * out_px + (unsigned)q * 16u;
 #pragma unroll
-            for (int m = 0; m < kStreamMT; ++m) stream_st(wb + (unsigned)m * out_px, zero_row ? kStreamZero : __builtin_bit_cast(f32x4, unit[m]));
+            for (int n = 0; n < NT; ++n)
+                if (2 * n + (q >> 1) < c.out.octs) {
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) stream_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, zero_row ? kStreamZero : __builtin_bit_cast(f32x4, unit[m][n]));
+                }
         }
+#ifdef S3_DBG
+        const long long tb = __builtin_readcyclecounter();
+        dbg_c += tb - dbg_t;
+#endif
         stream_barrier();
+#ifdef S3_DBG
+        dbg_t = __builtin_readcyclecounter();
+        dbg_b += dbg_t - tb;
+#endif
     }
+#ifdef S3_DBG
+    if (a.dbg && blockIdx.x == 0 && lane == 0) { long long* d = a.dbg + (threadIdx.x >> 6) * 4; d[0] = dbg_c; d[1] = dbg_b; d[2] = T; }
+#endif
 }
 
-// one workgroup = n_waves waves (pack.hip: the role table), one per CU (the rings take most of the LDS)
-__global__ __launch_bounds__(640) void feat3_stream(const Stream3Args a) {
+// one workgroup = n_waves <= 8 waves (CNN1 + one per conv; pack.hip: the role table), one per CU (the rings take most of the LDS)
+__global__ __launch_bounds__(512) void feat3_stream(const Stream3Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -238,14 +319,15 @@ __global__ __launch_bounds__(640) void feat3_stream(const Stream3Args a) {
     const int j1 = min(a.n_jobs, j0 + a.jobs_per_wg);
     const int rows = (j1 - j0) * (a.rows_c + 1);
     const int T = rows + a.total_lag;
-    const int ci = a.role_conv[wave], tile = a.role_tile[wave];
+    const int ci = a.role_conv[wave];
     if (ci < 0) s3_first_role(a, geo, lds0, j0, rows, T, lane);
     else {
+        const bool two = a.conv[ci].tiles == 2;
         switch (a.conv[ci].in.octs) {
-            case 1: s3_conv_role<1>(a, geo, ci, tile, lds0, j0, rows, T, lane); break;
-            case 2: s3_conv_role<2>(a, geo, ci, tile, lds0, j0, rows, T, lane); break;
-            case 3: s3_conv_role<3>(a, geo, ci, tile, lds0, j0, rows, T, lane); break;
-            default: s3_conv_role<4>(a, geo, ci, tile, lds0, j0, rows, T, lane); break;
+            case 1: if (two) s3_conv_role<1, 2>(a, geo, ci, lds0, j0, rows, T, lane); else s3_conv_role<1, 1>(a, geo, ci, lds0, j0, rows, T, lane); break;
+            case 2: if (two) s3_conv_role<2, 2>(a, geo, ci, lds0, j0, rows, T, lane); else s3_conv_role<2, 1>(a, geo, ci, lds0, j0, rows, T, lane); break;
+            case 3: if (two) s3_conv_role<3, 2>(a, geo, ci, lds0, j0, rows, T, lane); else s3_conv_role<3, 1>(a, geo, ci, lds0, j0, rows, T, lane); break;
+            default: if (two) s3_conv_role<4, 2>(a, geo, ci, lds0, j0, rows, T, lane); else s3_conv_role<4, 1>(a, geo, ci, lds0, j0, rows, T, lane); break;
         }
     }
 }

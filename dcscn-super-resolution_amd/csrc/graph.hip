@@ -715,14 +715,14 @@ void fuse_feat3_stream(dcscn_ctx* h) {
     const dcscn_config& c = h->cfg;
     const int L = c.layers;
     if (!h->stream_dense || c.depthwise_separable || c.cnn_size != 3 || L < 2 || L > kS3MaxL || (int)h->ops.size() < L) return;
-    int waves = 1;
+    int waves = 1;                                                // CNN1 + one per conv
     size_t lds = 0;
     for (int i = 0; i < L; ++i) {
         if (h->sched[i] > 32) return;
-        if (i > 0) waves += (h->sched[i] + 15) / 16;
-        if (i + 1 < L) lds += (size_t)3 * kStreamRowPx * (2 * ((h->sched[i] + 7) / 8) + 1) * 16;
+        if (i > 0) waves += 1;
+        if (i + 1 < L) lds += (size_t)4 * kStreamRowPx * (2 * ((h->sched[i] + 7) / 8) + 1) * 16;
     }
-    if (waves > kS3MaxWaves || lds > 150 * 1024) return;
+    if (waves > kS3MaxWaves || lds > 158 * 1024) return;
     const Op& c1 = h->ops[0];
     if (c1.kind != OP_CIN1 || c1.ks != 3 || c1.in_buf != EXT_X || c1.act != ACT_ALPHA || c1.out_off[0] != 0 || c1.out_buf[0] < 0 || c1.segs.size() != 1) return;
     for (int i = 1; i < L; ++i) {

@@ -236,8 +236,8 @@ hipError_t stream_launch(const StreamArgs& a, int grid, bool f16, hipStream_t st
 
 // ---- row-streamed feature extractor of the NON-separable narrow nets (feat3_stream.hpp) ----
 constexpr int kS3MaxL = 8;         // feature layers
-constexpr int kS3MaxWaves = 10;    // 1 (CNN1) + one per (conv, 16-channel output tile)
-struct S3Ring { int32_t off, px, octs; };              // LDS byte offset of [3 slots][kStreamRowPx][px bytes] P16 units; px = (2 octs + 1) * 16 (0: no ring)
+constexpr int kS3MaxWaves = 8;     // CNN1 + one per conv
+struct S3Ring { int32_t off, px, octs; };              // LDS byte offset of [4 slots][kStreamRowPx][px bytes] P16 units; px = (2 octs + 1) * 16 (0: no ring)
 struct S3Out {                     // a layer's global tensor: P16 (p16.base != nullptr) or float32 NHWC
     P16Desc p16;
     float* ptr;
@@ -265,6 +265,7 @@ struct Stream3Args {
     S3Out out[kS3MaxL];            // out[0] = CNN1's tensor, out[i + 1] = conv i's
     int32_t ring_bytes;
     int32_t* redo;                 // [0] pass flag, [1 + image] (split16.hpp)
+    long long* dbg;                // S3_DBG builds (tools/s3_abl.sh probe): per wave of workgroup 0: [0] cycles in compute, [1] cycles waiting at the barrier, [2] steps
 };
 hipError_t stream3_launch(const Stream3Args& a, int grid, hipStream_t stream);
 

@@ -755,7 +755,7 @@ int pack_feat3_stream(dcscn_ctx* h, Op& op) {
     for (int i = 0; i < L; ++i) {
         const int octs = (h->sched[i] + 7) / 8;
         ring[i] = S3Ring{lds, i + 1 < L ? (2 * octs + 1) * 16 : 0, octs};
-        if (i + 1 < L) lds += 3 * kStreamRowPx * ring[i].px;
+        if (i + 1 < L) lds += 4 * kStreamRowPx * ring[i].px;         // four slots (feat3_stream.hpp)
     }
     a.ring_bytes = lds;
     if (lds > 160 * 1024) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream needs %d bytes of LDS", lds);
@@ -818,10 +818,8 @@ int pack_feat3_stream(dcscn_ctx* h, Op& op) {
             blob[cv.ba_off + co] = std::ldexp(sg.b >= 0 ? tens(sg.b)[sg.col0 + co] : 0.0f, e);
             blob[cv.ba_off + 32 + co] = (sg.alpha >= 0 ? tens(sg.alpha)[sg.col0 + co] : o.const_alpha) - 1.0f;
         }
-        for (int n = 0; n < tiles; ++n) {
-            if (waves >= kS3MaxWaves) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream needs more than %d waves", kS3MaxWaves);
-            a.role_conv[waves] = (int8_t)(i - 1); a.role_tile[waves] = (int8_t)n; cost.push_back(9 * steps); ++waves;
-        }
+        if (waves >= kS3MaxWaves) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream needs more than %d waves", kS3MaxWaves);
+        a.role_conv[waves] = (int8_t)(i - 1); a.role_tile[waves] = 0; cost.push_back(9 * steps * tiles); ++waves;
     }
     a.n_waves = waves;
     {   // wave w runs on SIMD w & 3: deal the roles, heaviest first, onto the least loaded SIMD that has a wave slot left
