@@ -480,7 +480,7 @@ def main():
             # beside the headline: the same engine with float32 tensors between the split16 launches (p16 = 0: the r04 data path)
             try:
                 y_p16 = y.clone()
-                n_p16 = eng.num_p16_tensors()
+                n_p16 = eng.num_presplit_tensors()
                 eng.set_option("p16", 0)
                 for _ in range(max(args.warmup, 1)):
                     step()

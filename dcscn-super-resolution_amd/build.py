@@ -75,7 +75,7 @@ def build(force=False, verbose=False):
         src_path = os.path.join(CSRC, src)
         obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src_path] + HEADERS):
+        if force or _stale(obj, [src_path, os.path.abspath(__file__)] + HEADERS):       # (a change of the flag lists in this file rebuilds everything)
             jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-I", INCLUDE, "-c", src_path, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=len(jobs)) as pool:

@@ -698,7 +698,7 @@ int dcscn_debug_digests(dcscn_handle h, uint64_t* out, int capacity) {
 
 int64_t dcscn_workspace_bytes(dcscn_handle h) { return h ? (int64_t)h->arena_bytes : -1; }
 
-int dcscn_num_p16_tensors(dcscn_handle h) {
+int dcscn_num_presplit_tensors(dcscn_handle h) {
     if (!h) return -DCSCN_ERR_INVALID_ARG;
     if (!h->finalized || !p16_active(h)) return 0;
     int n = 0;

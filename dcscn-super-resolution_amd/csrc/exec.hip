@@ -556,6 +556,7 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
         capturing = false;
     };
     if (h->debug_digest) {
+        if (nops + 1 > 1024) return fail(h, DCSCN_ERR_UNSUPPORTED, "debug_digest: more than 1023 launches");
         if (!h->d_digest) HIP_TRY(h, hipMalloc((void**)&h->d_digest, 1024 * sizeof(unsigned long long)));
         HIP_TRY(h, hipMemsetAsync(h->d_digest, 0, 1024 * sizeof(unsigned long long), stream));
     }

@@ -86,7 +86,6 @@ struct ConvArgs {
     int32_t tail_octs;        // conv3_h: 0, or 1 / 2 / 3 = channel octets of the packed last chunk (c3h_tail_octs)
     int32_t redo_check;       // float32 kernels: 1 = the float32 plan behind a split16 pass -- only the units of flagged images are computed
     int32_t nt_pack;          // conv3_h8: channel tiles per group in the wpack16 image (the half of a workgroup may take fewer)
-    int32_t* work;            // conv3_hp (persistent workgroups): the launch's item counters, one per XCD at 64-byte spacing (8 x 16 ints), zero when the launch starts
 };
 
 struct ConvShape {            // kernel variant picked by the plan

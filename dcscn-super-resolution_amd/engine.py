@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = (
     "dcscn_abi_version", "dcscn_last_global_error", "dcscn_device_count", "dcscn_filter_schedule", "dcscn_create",
     "dcscn_num_tensors", "dcscn_tensor_info", "dcscn_set_tensor", "dcscn_finalize", "dcscn_num_layers",
     "dcscn_layer_info_get", "dcscn_num_ops", "dcscn_op_info_get", "dcscn_set_option", "dcscn_forward",
-    "dcscn_forward_device", "dcscn_forward_ensemble", "dcscn_get_profile", "dcscn_debug_digests", "dcscn_workspace_bytes", "dcscn_num_p16_tensors",
+    "dcscn_forward_device", "dcscn_forward_ensemble", "dcscn_get_profile", "dcscn_debug_digests", "dcscn_workspace_bytes", "dcscn_num_presplit_tensors",
     "dcscn_last_error", "dcscn_destroy", "dcscn_resize_bicubic", "dcscn_resize_bicubic_device", "dcscn_forward_lr",
     "dcscn_resample_table", "dcscn_get_stream", "dcscn_synchronize", "dcscn_convert_rgb_to_y", "dcscn_convert_rgb_to_ycbcr",
     "dcscn_convert_y_and_cbcr_to_rgb", "dcscn_evaluate_rgb", "dcscn_sr_rgb",
@@ -141,7 +141,7 @@ def load_library():
     lib.dcscn_get_profile.argtypes = [vp, dp, c.c_int]
     lib.dcscn_debug_digests.argtypes = [vp, c.POINTER(c.c_uint64), c.c_int]
     lib.dcscn_workspace_bytes.argtypes = [vp]
-    lib.dcscn_num_p16_tensors.argtypes = [vp]
+    lib.dcscn_num_presplit_tensors.argtypes = [vp]
     lib.dcscn_get_stream.argtypes = [vp, c.POINTER(vp)]
     u8p = c.POINTER(c.c_uint8)
     lib.dcscn_convert_rgb_to_y.argtypes = [vp, u8p, dp, c.c_int64]
@@ -497,6 +497,6 @@ class Engine:
     def workspace_bytes(self):
         return int(self._lib.dcscn_workspace_bytes(self._h))
 
-    def num_p16_tensors(self):
+    def num_presplit_tensors(self):
         """Workspace tensors the next forward keeps pre-split (option "p16", csrc/p16.hpp)."""
-        return int(self._lib.dcscn_num_p16_tensors(self._h))
+        return int(self._lib.dcscn_num_presplit_tensors(self._h))

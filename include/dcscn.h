@@ -292,7 +292,7 @@ int dcscn_debug_digests(dcscn_handle h, uint64_t* out, int capacity);
 int64_t dcscn_workspace_bytes(dcscn_handle h);
 /* How many workspace tensors the next forward keeps pre-split (option "p16"; 0 when the option, split16 or the graph rules it out).
  * The reference has no counterpart (sess.run hides its buffers); diagnostic for tests and benchmarks.  After dcscn_finalize. */
-int dcscn_num_p16_tensors(dcscn_handle h);
+int dcscn_num_presplit_tensors(dcscn_handle h);
 
 const char* dcscn_last_error(dcscn_handle h);
 int dcscn_destroy(dcscn_handle h);

@@ -799,10 +799,10 @@ def test_p16_tensors_are_bit_identical_to_float32_tensors(oracle, case):
         from dcscn_amd import engine
         with engine.Engine(cfg, device=0) as eng:
             eng.load_weights(weights, fold_tail=fold)
-            n16 = eng.num_p16_tensors()
+            n16 = eng.num_presplit_tensors()
             y1 = eng.forward(x, x2)
             eng.set_option("p16", 0)
-            assert eng.num_p16_tensors() == 0
+            assert eng.num_presplit_tensors() == 0
             y0 = eng.forward(x, x2)
             eng.set_option("p16", 1)
             eng.set_option("sub_batch_pixels", 2 * h * w)
@@ -827,7 +827,7 @@ def test_p16_overflow_recomputes_the_image_on_the_float32_plan(oracle):
     xb[1] *= 4000.0
     with engine.Engine(cfg, device=0) as eng:
         eng.load_weights(weights)
-        assert eng.num_p16_tensors() > 0
+        assert eng.num_presplit_tensors() > 0
         clean = eng.forward(x, x2)
         y = eng.forward(xb, x2)
         again = eng.forward(x, x2)

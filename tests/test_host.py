@@ -348,8 +348,11 @@ def test_library_has_no_packed_f32_instructions(tmp_path):
     from conftest import ROOT
     lib = os.path.join(ROOT, "dcscn-super-resolution_amd", "libdcscn_hip.so")
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not (os.path.isfile(lib) and os.path.isfile(objdump)):
-        pytest.skip("library or llvm-objdump not present")
+    # (every image this suite runs in carries ROCm's llvm-objdump: a missing tool is a failure, not a skip -- ADVICE r04 -- so that a
+    # toolchain change which drops the feature flag cannot pass unseen)
+    assert os.path.isfile(objdump), "llvm-objdump not found: the packed-f32 check cannot run"
+    if not os.path.isfile(lib):
+        pytest.skip("library not built")
     shutil.copy(lib, tmp_path / "lib.so")
     subprocess.run([objdump, "--offloading", "lib.so"], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True)
     objs = glob.glob(str(tmp_path / "lib.so.*gfx950*"))

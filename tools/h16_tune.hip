@@ -18,9 +18,6 @@
 #include "../dcscn-super-resolution_amd/csrc/split16_pack.hpp"
 #ifdef H16_CONV3
 #include "../dcscn-super-resolution_amd/csrc/conv3_h.hpp"
-#ifdef H16_HP
-#include "conv3_hp_lab.hpp"
-#endif
 #ifdef H16_H8
 #include "../dcscn-super-resolution_amd/csrc/conv3_h8.hpp"
 #endif

@@ -1,4 +1,4 @@
-// Correctness + timing harness for conv_wino2 (LDS-DMA staged Winograd) against a naive direct conv and the r01 kernel.
+// Correctness + timing harness for conv_wino2 (LDS-DMA staged Winograd) against a naive direct conv.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino2_tune.hip -o tools/wino2_tune
 //   ./tools/wino2_tune bench      every 3x3 layer of the bench model (L12_F196to48 x2), 1024 patches of 48x48
 //   ./tools/wino2_tune edge       ragged sizes, channel tails, narrow last groups, depth_to_space -- against the naive conv
@@ -10,7 +10,6 @@
 #include <cstring>
 #include <vector>
 
-#include "conv_wino_r01.hpp"
 #include "../dcscn-super-resolution_amd/csrc/conv_wino2.hpp"
 
 using namespace dcscn;
@@ -197,19 +196,7 @@ static Result run(const Layer& L, int N, int H, int W, int n_check, bool time_ol
                            g_bias, g_alpha, n_check, H, W, g_ref, L.out_stride, L.out_off, L.ps);
         CK(hipDeviceSynchronize());
     }
-    if (time_old) {
-        int nch, ng, ntl;
-        std::vector<float> p = pack_wino1(w, L.cin, L.cout, cin_phys, 3, &nch, &ng, &ntl);
-        CK(hipMemcpy(g_w, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
-        ConvArgs b = a;
-        b.wpack = g_w; b.n_chunks = nch; b.n_full = ntl;      // r01 kernel: tiles in the last group
-        b.out0 = OutDesc{g_out, L.out_stride, L.out_off, owidth};
-        b.out1 = b.out0;
-        const dim3 grid = wino_grid(b, ng);
-        auto kern = conv_wino<3, 4, 2>;
-        const size_t lds = (size_t)WinoGeom<3, 4>::BUF * sizeof(float);
-        r.ms_old = time_kernel(kern, grid, lds, b);
-    }
+    (void)time_old;       // (the r01 kernel this leg timed is gone from tools/; its numbers: profiles/r01_wino_tune_log.txt)
     {
         using G2 = Wino2Geom<NT>;
         int nch, ng, nt, nfull;
