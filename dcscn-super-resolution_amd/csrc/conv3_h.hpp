@@ -30,8 +30,8 @@
 // * a last chunk with at most 8 / 16 / 24 physical channels is PACKED: its (tap, octet) pairs go four to an instruction, 3 / 5 / 7
 //   MFMA steps instead of 9 (kernels.h: c3h_tail_octs; the host packs the filters to match).
 // * bias and slopes of the channel group are copied to LDS at workgroup start (no global round trip in the epilogue).
-// * epilogue: accumulators * 2^-e, bias, activator, optional depth_to_space addressing, float4 stores; non-finite outputs
-//   raise redo[pixel tile] for the f32 kernel launched behind this one (split16.hpp).
+// * epilogue: accumulators * 2^-e, bias, activator, optional depth_to_space addressing, float4 stores -- or, for a P16 destination
+//   (p16.hpp), one (hi | lo) unit per lane; a non-finite accumulator / hi piece raises the IMAGE's redo flag (split16.hpp).
 //
 #pragma once
 #include "conv_wino2.hpp"

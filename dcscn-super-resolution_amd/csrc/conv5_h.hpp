@@ -10,7 +10,7 @@
 //   one `vmcnt(0)` + barrier per column (60 NT MFMAs per wave).  Down a column the B rows slide as in conv3_h: 8 + 4 * 2 reads.
 // * LDS = 50 + NT * 20 KB: two workgroups per CU at NT = 1 (x2), one above.
 // * epilogue: conv_igemm's fold epilogue (phase = channel / 4, variant picked by the pixel's position on the image border,
-//   + x2, scalar store to y), accumulators * 2^-e; non-finite accumulators raise redo[tile] for conv_igemm<5,...> behind it.
+//   + x2, scalar store to y), accumulators * 2^-e; non-finite accumulators raise the image's redo flag (split16.hpp).
 #pragma once
 #include "conv3_h.hpp"
 

@@ -11,7 +11,8 @@
 // * S input stages (2 or 3): chunk c + S is fetched while chunk c computes; fragments of chunk c + 1 are read during chunk c;
 //   a chunk's filter pieces are issued before its input pieces so that the counted vmcnt wait covers them.
 // * filters: pack_conv16 image with one tap: [chunk][n][hi | lo][lane][8 halfs], 2 NT KB per chunk, two stages.
-// * epilogue as conv_nin plus the split16 parts (scale 2^-e, bias, activator, two destinations, redo flag per 256-pixel block = blockIdx.x / 2).
+// * epilogue as conv_nin plus the split16 parts (scale 2^-e, bias, activator, two destinations -- float32 or P16, each on its own --, the
+//   redo flag of the image of every pixel whose value left the f16 range).
 #pragma once
 #include "conv_nin.hpp"
 #include "split16.hpp"

@@ -13,14 +13,13 @@
 //   * filters are split ONCE on the host (split16_pack.hpp) after scaling the layer by a power of two 2^e that puts its
 //     largest weight in [2^13, 2^14): the lo pieces of all but vanishing weights stay normal f16 numbers.  The epilogue
 //     multiplies the accumulators by 2^-e (exact).
-//   * activations are split in registers, unscaled: |x| < 65520 is required for hi to be finite.  A value beyond that
-//     makes the accumulators of every output it feeds inf / NaN; the epilogue detects non-finite outputs and raises the
-//     `redo` flag of its unit (pixel block / pixel tile), and the f32 kernel launched behind it recomputes exactly the
-//     flagged units (and nothing else: it exits at once where the flag is clear).  So the path is safe for ANY finite f32
-//     input, and deterministic per unit whatever else is in the batch (a unit of the 1x1 GEMM is 256 consecutive pixels of the
-//     flat pixel list and can straddle two images: include/dcscn.h).  The flag is raised on NON-FINITE accumulators only -- the
-//     right trigger for |x| >= 65520; finite-but-huge inputs (6.5e4 > |x| >> 255) are covered by the 2^-22 relative bound of the
-//     split, not by the fallback.
+//   * activations are split unscaled -- in the consumer's registers, or (r05, p16.hpp) once, in the producer's epilogue: |x| < 65520 is
+//     required for hi to be finite.  A launch that meets a value beyond that (its accumulators turn inf / NaN) or produces one (a P16
+//     output whose hi piece is not finite) raises redo[0] and redo[1 + image]; behind the pass the float32 kernels of ALL launches run once
+//     more, gated by those flags (ConvArgs::redo_check): a flagged image is recomputed from the first layer on -- bit-identical to a
+//     split16 = 0 run of it -- and every other image keeps its bits (exec.hip: run_forward; r04 recomputed tiles per layer, which tensors
+//     holding (hi, lo) pairs no longer allow).  So the path is safe for ANY finite f32 input and deterministic per image whatever else is
+//     in the batch.  Finite-but-huge inputs (6.5e4 > |x| >> 255) are covered by the 2^-22 relative bound of the split, not by the fallback.
 #pragma once
 #include "conv_igemm.hpp"
 
