@@ -111,6 +111,7 @@ def load_image(filename, width=0, height=0, channels=0, alignment=0, print_conso
 _save_pool = None
 _save_pending = []
 _save_defer = 0
+_SAVE_MAX_PENDING = 64        # images in flight: a fast device path must not pile up uint8 copies faster than they are encoded
 
 
 def _encode_and_write(filename, image, mode):
@@ -136,11 +137,13 @@ def save_image(filename, image, print_console=True):
         if _save_pool is None:
             from concurrent.futures import ThreadPoolExecutor
             _save_pool = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
+        while len(_save_pending) >= _SAVE_MAX_PENDING:      # back-pressure: wait for the oldest write (its error, if any, surfaces here)
+            _save_pending.pop(0).result()
         _save_pending.append(_save_pool.submit(_encode_and_write, filename, image, mode))
     else:
         _encode_and_write(filename, image, mode)
     if print_console:
-        print("Saved [%s]" % filename)
+        print(("Queued [%s]" if _save_defer > 0 else "Saved [%s]") % filename)
 
 
 def flush_saves():
@@ -157,11 +160,15 @@ class deferred_saves(object):
         _save_defer += 1
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, exc, tb):
         global _save_defer
         _save_defer -= 1
         if _save_defer == 0:
-            flush_saves()
+            try:
+                flush_saves()
+            except Exception:
+                if exc_type is None:                          # (an exception from the block itself wins over a write error)
+                    raise
         return False
 
 

@@ -322,6 +322,8 @@ class SuperResolution:
             output = self.ensemble_group.ensemble_mean(
                 x[:, :, None], x2[:, :, None], self.self_ensemble,
                 lambda a, b: eng.forward(a[None], b[None])[0], util.flip)
+            if output is None:
+                return None                                   # not rank 0: the mean (and everything computed from it) lives there
         elif self.self_ensemble > 1:
             output = eng.forward_ensemble(x, x2, self.self_ensemble)            # float64, like np.zeros + +=
         else:
@@ -399,6 +401,8 @@ class SuperResolution:
             if true_y is None:
                 return None, None
             output = self.do(input_image, bicubic)
+            if output is None:
+                return 0.0, 0.0                               # split ensemble, not rank 0: the values are rank 0's (evaluate.py logs there)
         psnr, ssim = util.compute_psnr_and_ssim(true_y, output, border_size=self.psnr_calc_border_size)
         if print_console:
             print("[%s] PSNR:%f, SSIM:%f" % (file_path, psnr, ssim))

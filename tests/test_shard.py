@@ -52,9 +52,13 @@ for h, w in ((24, 40), (31, 17)):
     def forward_one(a, b):                      # stand-in for the device forward: any deterministic float32 function
         return (b * np.float32(0.75) + np.repeat(np.repeat(a, 2, 0), 2, 1) * np.float32(0.25) + np.float32(a.shape[0])).astype(np.float32)
     y = g.ensemble_mean(x, x2, 8, forward_one, imaging.flip)
-    assert y.dtype == np.float64 and y.shape == x2.shape
-    digests.append(hashlib.sha256(y.tobytes()).hexdigest())
-print("DIGEST", g.rank, " ".join(digests))
+    if g.rank == 0:
+        assert y.dtype == np.float64 and y.shape == x2.shape
+        digests.append(hashlib.sha256(y.tobytes()).hexdigest())
+    else:
+        assert y is None                        # the mean lives on rank 0 only
+if g.rank == 0:
+    print("DIGEST", g.rank, " ".join(digests))
 g.close()
 """
 
@@ -76,13 +80,13 @@ def _run_world(tmp_path, script_text, world):
 
 
 def test_sharded_self_ensemble_equals_the_one_rank_mean_bit_for_bit(tmp_path):
-    """The (image, transform) partition of evaluate.py on gloo with 1, 2 and 3 ranks: the float64 ensemble mean every rank ends
-    up with is bit-identical to the single-process one (transforms gathered, summed in the reference's order)."""
+    """The (image, transform) partition of evaluate.py on gloo with 1, 2 and 3 ranks: the float64 ensemble mean rank 0 ends
+    up with is bit-identical to the single-process one (transforms gathered there, summed in the reference's order)."""
     ref = None
     for world in (1, 2, 3):
         outs = _run_world(tmp_path, _ENSEMBLE_WORKER % ROOT, world)
         digs = {ln.split(" ", 2)[2] for o in outs for ln in o.splitlines() if ln.startswith("DIGEST")}
-        assert len(digs) == 1, outs                            # every rank holds the same mean
+        assert len(digs) == 1, outs                            # rank 0 holds the mean
         ref = ref or digs
         assert digs == ref, "world %d differs from world 1" % world
 
