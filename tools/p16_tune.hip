@@ -155,14 +155,19 @@ static R run_conv3(const Layer3& L, int N, int H, int W, bool timing, int overfl
                 CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, C3EGeom<C0>::LDS_BYTES));
                 hipLaunchKernelGGL(k, g8, dim3(512), C3EGeom<C0>::LDS_BYTES, 0, b);
             } else {
+#ifdef P16_TUNE_WIDE_ONLY
+                return;
+#endif
                 auto k = conv3_h8<C0, C1c, 0, (C0 >= 4 ? C0 : 0), false>;
                 CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, C3EGeom<C0>::LDS_BYTES));
                 hipLaunchKernelGGL(k, g8, dim3(512), C3EGeom<C0>::LDS_BYTES, 0, a);
             }
         };
 #define H8_CASE(A, B) if (c0 == A && c1 == B) { go(std::integral_constant<int, A>{}, std::integral_constant<int, B>{}); return; }
-        H8_CASE(6, 6) H8_CASE(6, 5) H8_CASE(5, 5) H8_CASE(5, 4) H8_CASE(4, 4) H8_CASE(4, 3)
-        H8_CASE(3, 3) H8_CASE(3, 2) H8_CASE(2, 2) H8_CASE(2, 1) H8_CASE(1, 1) H8_CASE(1, 0)
+        H8_CASE(6, 5) H8_CASE(5, 5) H8_CASE(5, 4) H8_CASE(4, 4) H8_CASE(4, 3)
+#ifndef P16_TUNE_WIDE_ONLY                  // (tuning builds: the five variants of the bench model's wide layers only -- a third of the compile time)
+        H8_CASE(6, 6) H8_CASE(3, 3) H8_CASE(3, 2) H8_CASE(2, 2) H8_CASE(2, 1) H8_CASE(1, 1) H8_CASE(1, 0)
+#endif
 #undef H8_CASE
         printf("no conv3_h8<%d, %d>\n", c0, c1); exit(1);
     };
@@ -221,6 +226,13 @@ int main(int argc, char** argv) {
         { R r = run_conv3(Layer3{"overflow", 57, 48}, 3, 40, 50, false, 1, false); ++n; bad += r.bad; }
         { R r = run_conv3(Layer3{"overflow", 133, 120}, 3, 40, 50, false, 1, false); ++n; bad += r.bad; }
         printf("p16 conv3 edge: %d cases, %d failures\n", n, bad);
+    }
+    if (!strcmp(what, "wide")) {             // tuning builds (-DP16_TUNE_WIDE_ONLY): the P16 kernel on CNN2 .. CNN7 only, no comparison
+        const Layer3 layers[] = {{"CNN2", 196, 166}, {"CNN3", 166, 148}, {"CNN4", 148, 133}, {"CNN5", 133, 120}, {"CNN6", 120, 108}, {"CNN7", 108, 97}};
+        double w16 = 0;
+        for (const Layer3& L : layers) { R r = run_conv3(L, 1024, 48, 48, true, 0, true); w16 += r.ms16; printf("%s %.3f  ", L.name, r.ms16); }
+        printf("\nCNN2-7 P16: %.3f ms\n", w16);
+        return 0;
     }
     if (!strcmp(what, "bench") || !strcmp(what, "all")) {
         const Layer3 layers[] = {{"CNN2", 196, 166}, {"CNN3", 166, 148}, {"CNN4", 148, 133}, {"CNN5", 133, 120}, {"CNN6", 120, 108}, {"CNN7", 108, 97},
