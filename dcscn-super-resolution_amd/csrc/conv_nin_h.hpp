@@ -22,6 +22,10 @@
 #define NINH_A_NT 0        // 1: input pieces with the non-temporal policy -- measured r05: 2.91 -> 4.18 ms (the producers' lines are still on their way through L2 / MALL)
 #endif
 
+#ifndef NINH_ABL
+#define NINH_ABL 0         // tuner only (tools/ninh_abl.sh; results wrong by design): 1 no filter DMA in the K loop, 2 no MFMAs, 4 no epilogue stores, 8 no input DMA in the K loop
+#endif
+
 namespace dcscn {
 
 template <int NT, int S = 2>
@@ -153,7 +157,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
         const unsigned Bs = b_lane + sb * G::B_STAGE;
         const unsigned An = a_lane + sn * G::A_BYTES, An2 = a_lane2 + sn * G::A_BYTES;
         // filters first, then input: the counted wait below relies on this order
-        static_for<0, G::B_ROUNDS>([&](auto r_) DCSCN_INL { dma_b(r_, cb, sb ^ 1); });
+        if constexpr (!(NINH_ABL & 1)) static_for<0, G::B_ROUNDS>([&](auto r_) DCSCN_INL { dma_b(r_, cb, sb ^ 1); });
         f32x4 na[G::MT], nb[G::MT];
         static_for<0, G::MT>([&](auto m_) DCSCN_INL {
             constexpr int m = decltype(m_)::value;
@@ -164,13 +168,16 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
                 constexpr int n = decltype(n_)::value;
                 const h8 wh = *(lds_h8_ptr)(uintptr_t)(Bs + (2 * n) * 1024);
                 const h8 wl = *(lds_h8_ptr)(uintptr_t)(Bs + (2 * n + 1) * 1024);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[m][n], 0, 0, 0);
+                if constexpr (NINH_ABL & 2) asm volatile("" :: "v"(wh), "v"(wl), "v"(xh), "v"(xl));
+                else {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[m][n], 0, 0, 0);
+                }
                 // the chunk's input pieces behind the first MFMA groups
-                if constexpr (m * NTV + n < G::A_ROUNDS) dma_a(std::integral_constant<int, m * NTV + n>{}, ca, sa);
+                if constexpr (!(NINH_ABL & 8) && m * NTV + n < G::A_ROUNDS) dma_a(std::integral_constant<int, m * NTV + n>{}, ca, sa);
             });
-            if constexpr (m == G::MT - 1 && G::MT * NTV < G::A_ROUNDS)
+            if constexpr (!(NINH_ABL & 8) && m == G::MT - 1 && G::MT * NTV < G::A_ROUNDS)
                 static_for<G::MT * NTV, G::A_ROUNDS>([&](auto r_) DCSCN_INL { dma_a(r_, ca, sa); });
             na[m] = *(lds_f32x4_ptr)(uintptr_t)(An + m * 16 * G::PSTRIDE);
             nb[m] = *(lds_f32x4_ptr)(uintptr_t)(An2 + m * 16 * G::PSTRIDE);
@@ -178,7 +185,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
         load_ent(chunk + S + 1 < last ? chunk + S + 1 : last);      // the next iteration's ca
         // the next chunk reads the fragments of chunk c + 2 and the filters of chunk c + 1: with S = 3 only this iteration's
         // input pieces (the youngest A_ROUNDS operations) may stay in flight
-        if constexpr (S == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (S == 2 || NINH_ABL != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::A_ROUNDS) : "memory");
         __syncthreads();
         static_for<0, G::MT>([&](auto m_) DCSCN_INL { xa[decltype(m_)::value] = na[decltype(m_)::value]; xb[decltype(m_)::value] = nb[decltype(m_)::value]; });
@@ -227,7 +234,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
                     v.w = activate1(v.w, av.w, act_e);
                     if (ACT_C < 0) chk[m] = nonfinite_acc(chk[m], acc[m][n], zero);
                     const u32x4 unit = p16_unit(v, m1, chk[m], zero2);
-                    if (p < npix && chan_ok) *reinterpret_cast<u32x4*>(base + (size_t)p * rec) = unit;
+                    if (p < npix && chan_ok && (!(NINH_ABL & 4) || unit.x == 0x12345u)) *reinterpret_cast<u32x4*>(base + (size_t)p * rec) = unit;
                 });
             } else if (cc < owidth) {
                 static_for<0, G::MT>([&](auto m_) DCSCN_INL {
@@ -238,7 +245,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
                     v.y = activate1(v.y, av.y, act_e);
                     v.z = activate1(v.z, av.z, act_e);
                     v.w = activate1(v.w, av.w, act_e);
-                    if (p < npix) {
+                    if (p < npix && (!(NINH_ABL & 4) || v.x == 12345.678f)) {
                         chk[m] = nonfinite_acc(chk[m], acc[m][n], zero);
                         *reinterpret_cast<f32x4*>(optr + (size_t)p * ostride + ooff + cc) = v;
                     }
