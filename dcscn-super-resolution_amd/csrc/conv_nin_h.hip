@@ -35,13 +35,13 @@ static hipError_t nin_h_launch_one(const ConvArgs& a, int n_groups, hipStream_t 
     if (a.in16.base) {                                           // P16 sources: a.srctab holds one entry per channel OCTET (4 per chunk)
         const size_t table = (size_t)a.n_chunks * 64;
         if (!a.srctab || table > (size_t)kNinHMaxTable || npix > kP16MaxPixels) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((conv_nin_h<NT, 2, kNinHStages>), grid, dim3(256), G::LDS_BYTES + table, stream, a);
+        hipLaunchKernelGGL((conv_nin_h<NT, 2, kNinHStages>), grid, dim3(NinHGeom<NT, kNinHStages>::THREADS), G::LDS_BYTES + table, stream, a);
     } else if (a.srctab) {
         const size_t table = (size_t)a.n_chunks * 128;           // 8 quads of 16 bytes per 32-channel chunk
         if (table > (size_t)kNinHMaxTable) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((conv_nin_h<NT, 1, kNinHStages>), grid, dim3(256), G::LDS_BYTES + table, stream, a);
+        hipLaunchKernelGGL((conv_nin_h<NT, 1, kNinHStages>), grid, dim3(NinHGeom<NT, kNinHStages>::THREADS), G::LDS_BYTES + table, stream, a);
     } else {
-        hipLaunchKernelGGL((conv_nin_h<NT, 0, kNinHStages>), grid, dim3(256), G::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((conv_nin_h<NT, 0, kNinHStages>), grid, dim3(NinHGeom<NT, kNinHStages>::THREADS), G::LDS_BYTES, stream, a);
     }
     return hipGetLastError();
 }

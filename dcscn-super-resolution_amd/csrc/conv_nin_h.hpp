@@ -28,20 +28,25 @@
 
 namespace dcscn {
 
+#ifndef NINH_WAVES
+#define NINH_WAVES 4       // waves per workgroup: 4 (two pixel tiles per wave) or 8 (one: half the serial work per wave and iteration, twice the waves per CU)
+#endif
+
 template <int NT, int S = 2>
 struct NinHGeom {
-    static constexpr int THREADS = 256;
+    static constexpr int W = NINH_WAVES;
+    static constexpr int THREADS = 64 * W;
     static constexpr int KC = 32;
     static constexpr int PIX = 128;
-    static constexpr int MT = 2;
+    static constexpr int MT = 8 / W;                          // 16-pixel tiles per wave
     static constexpr int PSTRIDE = 128;
     static constexpr int A_SLOTS = PIX * 8;
     static constexpr int A_DMA = A_SLOTS / 64;                // 16 wave instructions, 4 per wave
     static constexpr int A_BYTES = A_SLOTS * 16;              // 16384
-    static constexpr int A_ROUNDS = A_DMA / 4;
+    static constexpr int A_ROUNDS = A_DMA / W;
     static constexpr int B_BYTES = NT * 2048;
     static constexpr int B_PIECES = 2 * NT;
-    static constexpr int B_ROUNDS = (B_PIECES + 3) / 4;
+    static constexpr int B_ROUNDS = (B_PIECES + W - 1) / W;
     static constexpr int B_STAGE = B_BYTES;
     static constexpr int B_BASE = S * A_BYTES;
     static constexpr int BA_BASE = S * A_BYTES + 2 * B_STAGE;  // bias | slopes of the channel group (NT * 16 floats each), staged at workgroup start
@@ -75,7 +80,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
     long long a_pix[G::A_ROUNDS];
     static_for<0, G::A_ROUNDS>([&](auto r_) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
-        long long p = pix0 + (wave + 4 * r) * 8 + (lane >> 3);
+        long long p = pix0 + (wave + G::W * r) * 8 + (lane >> 3);
         p = p < npix ? p : npix - 1;
         a_pix[r] = p;
         a_off[r] = (unsigned)((p - pix0) * a.in_stride * 4);
@@ -86,7 +91,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
 
     auto dma_b = [&](auto r_, int chunk, unsigned stage) DCSCN_INL {
         constexpr int r = decltype(r_)::value;
-        const int piece = (wave + 4 * r) % G::B_PIECES;       // waves without a piece of their own repeat one: same count for every wave
+        const int piece = (wave + G::W * r) % G::B_PIECES;       // waves without a piece of their own repeat one: same count for every wave
         glds16(b_base + (size_t)chunk * G::B_BYTES + 1024 * piece, b_off, lds0 + G::B_BASE + stage * G::B_STAGE + (unsigned)piece * 1024u);
     };
     typedef const volatile __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
@@ -99,11 +104,11 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
         constexpr int r = decltype(r_)::value;
         if constexpr (MULTI) {
             const char* src = reinterpret_cast<const char*>(((unsigned long long)ent.y << 32) | ent.x) + (unsigned long long)a_pix[r] * ent.z + (IN16 ? (dq & 1) * 16 : 0);
-            if constexpr (NINH_A_NT) glds16v_nt(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
-            else glds16v(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
+            if constexpr (NINH_A_NT) glds16v_nt(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + G::W * r) * 1024u);
+            else glds16v(src, lds0 + stage * G::A_BYTES + (unsigned)(wave + G::W * r) * 1024u);
         } else {
             const int c0 = chunk * G::KC + 4 * dq;
-            glds16(a_base, a_off[r] + (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4), lds0 + stage * G::A_BYTES + (unsigned)(wave + 4 * r) * 1024u);
+            glds16(a_base, a_off[r] + (unsigned)((c0 < a.cin_phys ? c0 : 0) * 4), lds0 + stage * G::A_BYTES + (unsigned)(wave + G::W * r) * 1024u);
         }
     };
 
@@ -123,8 +128,8 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
         static_for<0, NTV>([&](auto n_) DCSCN_INL { acc[decltype(m_)::value][decltype(n_)::value] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; });
     });
 
-    // B fragment of pixel tile m: pixel 32 * wave + 16 * m + lj, channel group lk: halves at slot 2 * ((lk + (pixel >> 1)) & 3) + (lk & 1), ^ 1
-    const unsigned a_rel = (unsigned)((32 * wave + lj) * G::PSTRIDE + ((((lk + (lj >> 1)) & 3) << 1) | (lk & 1)) * 16);
+    // B fragment of pixel tile m: pixel 16 * G::MT * wave + 16 * m + lj, channel group lk: halves at slot 2 * ((lk + (pixel >> 1)) & 3) + (lk & 1), ^ 1
+    const unsigned a_rel = (unsigned)((16 * G::MT * wave + lj) * G::PSTRIDE + ((((lk + (lj >> 1)) & 3) << 1) | (lk & 1)) * 16);
     const unsigned a_lane = lds0 + a_rel, a_lane2 = lds0 + (a_rel ^ 16u);
     const unsigned b_lane = lds0 + (unsigned)(G::B_BASE + lane * 16);
     typedef const volatile __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
@@ -226,7 +231,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
                 const bool chan_ok = oct0 + (lk >> 1) < od.p16.octs;
                 static_for<0, G::MT>([&](auto m_) DCSCN_INL {
                     constexpr int m = decltype(m_)::value;
-                    const long long p = pix0 + 32 * wave + 16 * m + lj;
+                    const long long p = pix0 + 16 * G::MT * wave + 16 * m + lj;
                     f32x4 v = acc[m][n] * inv + bv;
                     v.x = activate1(v.x, av.x, act_e);
                     v.y = activate1(v.y, av.y, act_e);
@@ -239,7 +244,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
             } else if (cc < owidth) {
                 static_for<0, G::MT>([&](auto m_) DCSCN_INL {
                     constexpr int m = decltype(m_)::value;
-                    const long long p = pix0 + 32 * wave + 16 * m + lj;
+                    const long long p = pix0 + 16 * G::MT * wave + 16 * m + lj;
                     f32x4 v = acc[m][n] * inv + bv;
                     v.x = activate1(v.x, av.x, act_e);
                     v.y = activate1(v.y, av.y, act_e);
@@ -261,7 +266,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
     static_for<0, G::MT>([&](auto m_) DCSCN_INL {
         constexpr int m = decltype(m_)::value;
         if (chk[m] != chk[m] && a.redo) {
-            long long p = pix0 + 32 * wave + 16 * m + lj;
+            long long p = pix0 + 16 * G::MT * wave + 16 * m + lj;
             p = p < npix ? p : npix - 1;
             a.redo[0] = 1;
             a.redo[1 + (int)(p / ((long long)a.H * a.W))] = 1;
@@ -271,7 +276,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
 
 // grid = (pixel blocks of 128, channel groups)
 template <int NT, int SRC = 0, int S = 2, int WPS = 2>
-__global__ __launch_bounds__(256, WPS) void conv_nin_h(const ConvArgs a) {
+__global__ __launch_bounds__(64 * NINH_WAVES, WPS * NINH_WAVES / 4) void conv_nin_h(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const long long pix0 = (long long)blockIdx.x * NinHGeom<NT, S>::PIX;
     const int ntile = blockIdx.y;
