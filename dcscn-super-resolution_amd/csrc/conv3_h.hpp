@@ -445,6 +445,40 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
                 bx = sub - ay * ps;
             }
             const bool live = gx < W && cc < owidth;
+            if (!a.vec4) {
+                // block uniform: destinations without the 16-byte store form (a pixel shuffler to fewer than 4 channels per sub-pixel -- the
+                // x3 stage of the c-DCSCN nets, 32 -> 9 -- or a width that is no multiple of 4): one store per channel
+                static_for<0, 4>([&](auto m_) DCSCN_INL {
+                    constexpr int m = decltype(m_)::value;
+                    const int gy = y0 + 4 * wave + m;
+                    f32x4 v = acc[m][n] * inv + bv;
+                    v.x = activate1(v.x, av.x, act_e);
+                    v.y = activate1(v.y, av.y, act_e);
+                    v.z = activate1(v.z, av.z, act_e);
+                    v.w = activate1(v.w, av.w, act_e);
+                    if (gx < W && gy < H) {
+                        chk = nonfinite_acc(chk, acc[m][n], zero);
+                        static_for<0, 4>([&](auto i_) DCSCN_INL {
+                            constexpr int i = decltype(i_)::value;
+                            const int cci = cc + i;
+                            if (cci < owidth) {
+                                int chi = cci, ayi = 0, bxi = 0;
+                                if (ps != 1) {
+                                    const int sub = cci / a.ps_c;
+                                    chi = cci - sub * a.ps_c;
+                                    ayi = sub / ps;
+                                    bxi = sub - ayi * ps;
+                                }
+                                const size_t pix = (size_t)((img * H + gy) * ps + ayi) * orow + (size_t)(gx * ps + bxi);
+                                float r = i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+                                if (a.res) r += a.res[pix * a.res_stride + chi];
+                                optr[pix * ostride + ooff + chi] = r;
+                            }
+                        });
+                    }
+                });
+                return;
+            }
             static_for<0, 4>([&](auto m_) DCSCN_INL {
                 constexpr int m = decltype(m_)::value;
                 const int gy = y0 + 4 * wave + m;
@@ -574,7 +608,7 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
         if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + img] = 1; }
         return;
     }
-    const bool fast = ps == 1 && a.res == nullptr && (a.split & 15) == 0 && whole_tile;   // block uniform
+    const bool fast = ps == 1 && a.res == nullptr && (a.split & 15) == 0 && whole_tile && a.vec4;   // block uniform
     if (fast && act == ACT_ALPHA) finish_fast(std::integral_constant<int, ACT_ALPHA>{});
     else if (fast && act == ACT_NONE) finish_fast(std::integral_constant<int, ACT_NONE>{});
     else if (act == ACT_ALPHA) finish(std::integral_constant<int, ACT_ALPHA>{});

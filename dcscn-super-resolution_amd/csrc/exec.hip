@@ -314,6 +314,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
             b.bias = op.h16.d_bias;
             b.tail_octs = op.h16.tail_octs;
             b.alpha = op.h16.d_alpha;
+            b.tiles_y = (Hr + 15) / 16;                           // (16 x 16 pixel tiles whatever the float32 kernel behind the layer uses)
             if (op_takes_h8(h, op)) HIP_TRY(h, c3e_launch(op.h16.nt, b, op.h16.n_tiles, h->n_cus, stream));
             else HIP_TRY(h, c3h_launch(op.h16.nt, b, op.h16.n_tiles, stream));
         }

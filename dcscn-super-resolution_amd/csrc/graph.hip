@@ -467,6 +467,15 @@ bool wino_eligible(const dcscn_ctx* h, const Op& op) {
            op.segs.size() == 1 && op.tconv_s == 0 && tiles16 >= 2;
 }
 
+// 3x3 layers the Winograd kernel does not take because they have ONE 16-channel tile or a destination without the 16-byte store form
+// (a pixel shuffler to fewer than 4 channels per sub-pixel: the x3 stage of the c-DCSCN nets, 32 -> 9) still go to conv3_h under split16:
+// one tile of the direct form on the f16 pipe against conv_igemm's f32 rate (0.41 -> 0.13 ms on that layer); conv_igemm stays behind
+// them as the float32 kernel (split16 = 0, flagged images)
+bool h16_direct_eligible(const dcscn_ctx* h, const Op& op) {
+    return h->winograd && !wino_eligible(h, op) && op.kind == OP_CONV && op.ks == 3 && op.dwk == 0 && op.cin_phys >= 24 && op.segs.size() == 1 &&
+           op.tconv_s == 0 && op.fold_s == 0 && op.in_stride_override <= 0;
+}
+
 // ---- optional graph rewrite: the linear tail as one conv ----------------------------------------
 //
 // The last pixel-shuffler stage (3x3 conv + bias, NO activator, DCSCN.py:293-311), depth_to_space and the

@@ -16,6 +16,45 @@ int upload(dcscn_ctx* h, const void* host, size_t bytes, void** dev) {
 }
 
 
+// conv3_h's image of a 3x3 layer (one column segment): direct form on the f16 pipe with its own channel groups (up to kC3hMaxNT tiles),
+// untransformed filters as (hi, lo) fragments scaled by 2^e, bias and slopes in the padded group layout
+static int pack_conv3_h16(dcscn_ctx* h, Op& op, const TensorSpec& tw, int wcols, int tiles16) {
+    const ColSeg& sg = op.segs[0];
+    const int cin = (int)op.chan_map.size();
+    Op::Split16& s16 = op.h16;
+    s16.n_tiles = (tiles16 + kC3hMaxNT - 1) / kC3hMaxNT;
+    s16.nt = (tiles16 + s16.n_tiles - 1) / s16.n_tiles;
+    s16.n_full = tiles16 - s16.n_tiles * (s16.nt - 1);
+    s16.n_chunks = (op.cin_phys + kC3hKC - 1) / kC3hKC;
+    const int nt16 = s16.nt, ctot16 = s16.n_tiles * nt16 * 16;
+    auto padded16 = [&](int cc) {
+        const int t = cc / 16;
+        const int wide = s16.n_full * nt16;
+        const int g = t < wide ? t / nt16 : s16.n_full + (t - wide) / (nt16 - 1);
+        const int tg = t < wide ? t % nt16 : (t - wide) % (nt16 - 1);
+        return (g * nt16 + tg) * 16 + cc % 16;
+    };
+    std::vector<float> dense((size_t)9 * op.cin_phys * ctot16, 0.0f), b16(ctot16, 0.0f), a16(ctot16, 0.0f);
+    for (int t = 0; t < 9; ++t)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < sg.cout; ++co)
+                dense[((size_t)t * op.cin_phys + op.chan_map[ci]) * ctot16 + padded16(sg.dst + co)] = tw.data[((size_t)t * cin + ci) * wcols + sg.col0 + co];
+    for (int co = 0; co < sg.cout; ++co) {
+        const int pc = padded16(sg.dst + co);
+        if (sg.b >= 0) b16[pc] = h->tensors[sg.b].data[sg.col0 + co];
+        a16[pc] = sg.alpha >= 0 ? h->tensors[sg.alpha].data[sg.col0 + co] : op.const_alpha;
+    }
+    const int e = split16_scale_exp(dense.data(), dense.size());
+    s16.inv_scale = std::ldexp(1.0f, -e);
+    s16.tail_octs = c3h_tail_octs(op.cin_phys);
+    const std::vector<uint16_t> img = pack_conv16(dense, 9, op.cin_phys, ctot16, s16.n_tiles, nt16, s16.n_chunks, e, s16.tail_octs);
+    int rc = upload(h, img.data(), img.size() * sizeof(uint16_t), &s16.d_w);
+    if (!rc) rc = upload(h, b16.data(), b16.size() * sizeof(float), (void**)&s16.d_bias);
+    if (!rc) rc = upload(h, a16.data(), a16.size() * sizeof(float), (void**)&s16.d_alpha);
+    s16.on = rc == DCSCN_OK;
+    return rc;
+}
+
 int finalize_op(dcscn_ctx* h, Op& op) {
     if (op.kind == OP_STREAM3) return pack_feat3_stream(h, op);
     if (op.kind == OP_STREAM) return pack_feat_stream(h, op);
@@ -236,40 +275,7 @@ int finalize_op(dcscn_ctx* h, Op& op) {
         int rcw = upload(h, pack.data(), pack.size() * sizeof(float), (void**)&op.d_w);
         if (!rcw) rcw = upload(h, bias.data(), bias.size() * sizeof(float), (void**)&op.d_bias);
         if (!rcw) rcw = upload(h, alpha.data(), alpha.size() * sizeof(float), (void**)&op.d_alpha);
-        if (!rcw) {
-            // conv3_h: direct 3x3 on the f16 pipe with its own channel groups (up to kC3hMaxNT tiles), untransformed filters
-            Op::Split16& s16 = op.h16;
-            s16.n_tiles = (tiles16 + kC3hMaxNT - 1) / kC3hMaxNT;
-            s16.nt = (tiles16 + s16.n_tiles - 1) / s16.n_tiles;
-            s16.n_full = tiles16 - s16.n_tiles * (s16.nt - 1);
-            s16.n_chunks = (op.cin_phys + kC3hKC - 1) / kC3hKC;
-            const int nt16 = s16.nt, ctot16 = s16.n_tiles * nt16 * 16;
-            auto padded16 = [&](int cc) {
-                const int t = cc / 16;
-                const int wide = s16.n_full * nt16;
-                const int g = t < wide ? t / nt16 : s16.n_full + (t - wide) / (nt16 - 1);
-                const int tg = t < wide ? t % nt16 : (t - wide) % (nt16 - 1);
-                return (g * nt16 + tg) * 16 + cc % 16;
-            };
-            std::vector<float> dense((size_t)9 * op.cin_phys * ctot16, 0.0f), b16(ctot16, 0.0f), a16(ctot16, 0.0f);
-            for (int t = 0; t < 9; ++t)
-                for (int ci = 0; ci < cin; ++ci)
-                    for (int co = 0; co < sg.cout; ++co)
-                        dense[((size_t)t * op.cin_phys + op.chan_map[ci]) * ctot16 + padded16(sg.dst + co)] = tw.data[((size_t)t * cin + ci) * wcols + sg.col0 + co];
-            for (int co = 0; co < sg.cout; ++co) {
-                const int pc = padded16(sg.dst + co);
-                if (sg.b >= 0) b16[pc] = h->tensors[sg.b].data[sg.col0 + co];
-                a16[pc] = sg.alpha >= 0 ? h->tensors[sg.alpha].data[sg.col0 + co] : op.const_alpha;
-            }
-            const int e = split16_scale_exp(dense.data(), dense.size());
-            s16.inv_scale = std::ldexp(1.0f, -e);
-            s16.tail_octs = c3h_tail_octs(op.cin_phys);
-            const std::vector<uint16_t> img = pack_conv16(dense, 9, op.cin_phys, ctot16, s16.n_tiles, nt16, s16.n_chunks, e, s16.tail_octs);
-            rcw = upload(h, img.data(), img.size() * sizeof(uint16_t), &s16.d_w);
-            if (!rcw) rcw = upload(h, b16.data(), b16.size() * sizeof(float), (void**)&s16.d_bias);
-            if (!rcw) rcw = upload(h, a16.data(), a16.size() * sizeof(float), (void**)&s16.d_alpha);
-            s16.on = rcw == DCSCN_OK;
-        }
+        if (!rcw) rcw = pack_conv3_h16(h, op, tw, wcols, tiles16);
         return rcw;
     }
     const int max_nt = op.dwk ? conv_max_fused_dw_nt() : conv_max_nt(op.ks);
@@ -343,6 +349,8 @@ int finalize_op(dcscn_ctx* h, Op& op) {
             s16.on = rc == DCSCN_OK;
         }
     }
+    // one-tile / scalar-store 3x3 layers: conv3_h in front of the conv_igemm kernel packed above (graph.hip: h16_direct_eligible)
+    if (!rc && h16_direct_eligible(h, op)) rc = pack_conv3_h16(h, op, h->tensors[op.segs[0].w], (int)h->tensors[op.segs[0].w].shape.back(), tiles16);
     return rc;
 }
 

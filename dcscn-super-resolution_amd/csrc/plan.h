@@ -250,6 +250,7 @@ int build_graph(dcscn_ctx* h);
 int op_tiles16(const Op& op);
 bool nin_eligible(const dcscn_ctx* h, const Op& op);
 bool wino_eligible(const dcscn_ctx* h, const Op& op);
+bool h16_direct_eligible(const dcscn_ctx* h, const Op& op);
 bool fold_linear_tail(dcscn_ctx* h);
 int stream_chunk_channel(int quads, int ch, int q, int s);
 bool stream_conv_supported(int in_quads, int out_tiles);
