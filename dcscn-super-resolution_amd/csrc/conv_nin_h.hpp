@@ -29,16 +29,19 @@
 namespace dcscn {
 
 #ifndef NINH_WAVES
-#define NINH_WAVES 4       // waves per workgroup: 4 (two pixel tiles per wave) or 8 (one: half the serial work per wave and iteration, twice the waves per CU)
+#define NINH_WAVES 4       // waves per workgroup (tuner: 8)
 #endif
+#ifndef NINH_MT
+#define NINH_MT 2          // 16-pixel tiles per wave; pixels per workgroup = 16 * NINH_MT * NINH_WAVES (tuner: 8 waves x 1 = 128 pixels with half the serial work
+#endif                     // per wave; 8 x 2 = 256 pixels, ONE workgroup per CU, half the filter traffic per pixel)
 
 template <int NT, int S = 2>
 struct NinHGeom {
     static constexpr int W = NINH_WAVES;
     static constexpr int THREADS = 64 * W;
     static constexpr int KC = 32;
-    static constexpr int PIX = 128;
-    static constexpr int MT = 8 / W;                          // 16-pixel tiles per wave
+    static constexpr int PIX = 16 * NINH_MT * W;
+    static constexpr int MT = NINH_MT;                        // 16-pixel tiles per wave
     static constexpr int PSTRIDE = 128;
     static constexpr int A_SLOTS = PIX * 8;
     static constexpr int A_DMA = A_SLOTS / 64;                // 16 wave instructions, 4 per wave
@@ -276,7 +279,7 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
 
 // grid = (pixel blocks of 128, channel groups)
 template <int NT, int SRC = 0, int S = 2, int WPS = 2>
-__global__ __launch_bounds__(64 * NINH_WAVES, WPS * NINH_WAVES / 4) void conv_nin_h(const ConvArgs a) {
+__global__ __launch_bounds__(64 * NINH_WAVES, (WPS * NINH_WAVES / 4) * 128 / (16 * NINH_MT * NINH_WAVES) > 0 ? (WPS * NINH_WAVES / 4) * 128 / (16 * NINH_MT * NINH_WAVES) : 1) void conv_nin_h(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const long long pix0 = (long long)blockIdx.x * NinHGeom<NT, S>::PIX;
     const int ntile = blockIdx.y;
