@@ -534,7 +534,7 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
             });
         });
     };
-    // P16 destination(s) (plain NHWC geometry: no depth_to_space, no residual): one (hi | lo) unit per lane and tile, one 64-bit base per
+    // P16 destination(s) (no residual; depth_to_space when a sub-pixel takes whole tiles): one (hi | lo) unit per lane and tile, one 64-bit base per
     // tile and 32-bit lane offsets; a float32 destination beside a P16 one takes the plain store
     auto finish16 = [&](auto act_c, auto mask_c) DCSCN_INL {
         constexpr int ACT_C = decltype(act_c)::value;
@@ -559,13 +559,22 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
             bool chan_ok;
             const bool o16 = od.p16.base != nullptr;              // block uniform
             if (o16) {
-                const int oct0 = (od.off + cc0) >> 3;
+                // depth_to_space (ps_c a multiple of 16: the tile lies in ONE sub-pixel (ay, bx)): pixel (y, x) -> (y ps + ay, x ps + bx) of the
+                // ps-times larger map; the lane offsets stay 32-bit
+                int ch0 = cc0, ay = 0, bx = 0;
+                if (ps != 1) {
+                    const int sub = cc0 / a.ps_c;
+                    ch0 = cc0 - sub * a.ps_c;
+                    ay = sub / ps;
+                    bx = sub - ay * ps;
+                }
+                const int oct0 = (od.off + ch0) >> 3;
                 const int chunk = oct0 >> 2, rem = od.p16.octs - 4 * chunk;
                 const int rec = rem >= 4 ? 128 : 32 * rem;
-                base = od.p16.base + (long long)chunk * od.p16.plane + 128 + (long long)((img * H + y0) * W + x0) * rec + (oct0 & 3) * 32;
-                voff = (unsigned)((4 * wave * W + lje) * rec + lke * 16);
-                rowb = (unsigned)(W * rec);
-                chan_ok = col_ok && oct0 + (lke >> 1) < od.p16.octs;
+                base = od.p16.base + (long long)chunk * od.p16.plane + 128 + ((long long)((img * H + y0) * ps + ay) * orow + x0 * ps + bx) * rec + (oct0 & 3) * 32;
+                voff = (unsigned)((4 * wave * ps * orow + lje * ps) * rec + lke * 16);
+                rowb = (unsigned)(ps * orow * rec);
+                chan_ok = col_ok && oct0 + (lke >> 1) < od.p16.octs && ay < ps;
             } else {
                 base = reinterpret_cast<char*>(od.ptr + ((size_t)(img * H + y0) * W + x0) * od.stride + od.off + cc0);
                 voff = (unsigned)(((4 * wave * W + lje) * od.stride + 4 * lke) * 4);

@@ -771,7 +771,7 @@ void fuse_feat3_stream(dcscn_ctx* h) {
 
 // ---- P16 tensors (p16.hpp) ----------------------------------------------------------------------------
 // A workspace tensor is kept in the pre-split form when EVERY launch that writes it can store (hi | lo) units -- conv_cin1, conv3_h,
-// conv3_h8, conv_nin_h with a plain NHWC destination on a 16-channel boundary -- and EVERY launch that reads it is a split16 kernel
+// conv3_h8, conv_nin_h with a plain NHWC destination on a 16-channel boundary, conv3_h through a pixel shuffler to >= 16 channels -- and EVERY launch that reads it is a split16 kernel
 // reading the whole tensor from channel 0 in its natural channel order (conv3_h / conv3_h8 / conv5_h; conv_nin_h when ALL its sources
 // qualify).  Fixed point over the launch list; runs after finalize_op (it needs to know which launches have a split16 variant).
 void plan_p16(dcscn_ctx* h) {
@@ -796,7 +796,9 @@ void plan_p16(dcscn_ctx* h) {
     auto can_write = [&](const Op& op, int k) {
         if (op.kind == OP_STREAM3) return op.h16.on;             // (stores P16 units or float32, per tensor)
         if (op.kind == OP_CIN1) return k == 0 && op.out_off[0] == 0 && op.ks <= 3;   // (conv_cin1's octet-per-thread store path holds 2 x taps filter quads)
-        if (op.kind != OP_CONV || !op.h16.on || op.fold_s > 0 || op.ps != 1 || op.residual || op.dwk != 0) return false;
+        if (op.kind != OP_CONV || !op.h16.on || op.fold_s > 0 || op.residual || op.dwk != 0) return false;
+        // a pixel shuffler whose sub-pixels take whole 16-channel tiles (conv3_h's P16 epilogue with depth_to_space addressing): ONE destination
+        if (op.ps != 1 && (op.shape.nin || op.ps_c % 16 != 0 || k != 0 || op.split < (1 << 29))) return false;
         if (op.out_off[k] % 16 != 0) return false;
         return k == 0 || op.split % 16 == 0;
     };
