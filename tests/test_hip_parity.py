@@ -182,6 +182,17 @@ def test_ragged_sizes(oracle, hw, split16):
     _check(oracle, "wide-odd", dict(layers=3, filters=70, min_filters=45, nin_filters=40, nin_filters2=33), 1, hw[0], hw[1], split16=split16)
 
 
+@pytest.mark.parametrize("split16", SPLIT16)
+@pytest.mark.parametrize("hw", [(5, 7), (17, 33), (50, 20)])
+def test_ragged_sizes_through_the_shuffler_epilogues(oracle, hw, split16):
+    """The two conv3_h store paths r05 added, on sizes that cut the 16 x 16 pixel tiles: per-channel stores for a pixel shuffler to ONE
+    channel per sub-pixel (x3 c-DCSCN: Up-PS 32 -> 9 as a one-tile layer, graph.hip h16_direct_eligible) and (hi | lo) units stored with
+    depth_to_space addressing (x4 nets: the half-resolution map stays pre-split for conv5_h)."""
+    _check(oracle, "L7_F32to8_x3", dict(CONFIGS["L7_F32to8_x2"], scale=3), 2, hw[0], hw[1], split16=split16)
+    _check(oracle, "L7_F32to8_x4", dict(CONFIGS["L7_F32to8_x2"], scale=4), 2, hw[0], hw[1], split16=split16)
+    _check(oracle, "wide-x4", dict(layers=3, filters=70, min_filters=45, nin_filters=40, nin_filters2=24, scale=4), 1, hw[0], hw[1], split16=split16)
+
+
 def test_sub_batching_is_transparent(oracle):
     """Splitting the batch into passes must not change a single bit (no cross-image coupling)."""
     cfg = oracle.make_config(**CONFIGS["L7_F32to8_x2"])
@@ -782,6 +793,11 @@ P16_CASES = [
     ("wide-odd", dict(layers=3, filters=70, min_filters=45, nin_filters=40, nin_filters2=33), 2, 17, 33),   # Concat2 slice off a 16-channel boundary
     ("odd-channels", dict(layers=4, filters=37, min_filters=13, nin_filters=21, nin_filters2=10), 2, 20, 50),
     ("three-groups", dict(layers=3, filters=250, min_filters=120, nin_filters=64, nin_filters2=32), 1, 24, 40),
+    # the half-resolution map of an x4 net stays pre-split through the pixel shuffler (conv3_h's P16 epilogue with depth_to_space addressing)
+    ("c-DCSCN-x4", dict(layers=7, filters=32, min_filters=8, filters_decay_gamma=1.2, nin_filters=24, nin_filters2=8, reconstruct_layers=0,
+                        pixel_shuffler_filters=1, scale=4), 2, 21, 35),
+    ("c-DCSCN-x3", dict(layers=7, filters=32, min_filters=8, filters_decay_gamma=1.2, nin_filters=24, nin_filters2=8, reconstruct_layers=0,
+                        pixel_shuffler_filters=1, scale=3), 2, 21, 35),
 ]
 
 
@@ -813,6 +829,27 @@ def test_p16_tensors_are_bit_identical_to_float32_tensors(oracle, case):
         assert float(np.max(np.abs(y1 - ref))) <= MAX_ABS_TOL
         assert np.array_equal(y1, y0), "p16 on / off differ in %d values" % int(np.sum(y1 != y0))
         assert np.array_equal(y1, y2)
+
+
+def test_one_tile_shuffler_layer_runs_on_conv3_h(oracle):
+    """x3 c-DCSCN: Up-PS is a 3x3 conv 32 -> 9 in front of a pixel shuffler to ONE channel -- one 16-channel tile, no 16-byte stores.  Under
+    split16 it runs on conv3_h (per-channel store epilogue), conv_igemm stays behind it as the float32 kernel."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(layers=7, filters=32, min_filters=8, filters_decay_gamma=1.2, nin_filters=24, nin_filters2=8, reconstruct_layers=0,
+                             pixel_shuffler_filters=1, scale=3)
+    weights = oracle.synthetic_weights(cfg, seed=2)
+    x, x2 = synthetic_batch(2, 19, 23, 3, seed=5)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    with engine.Engine(cfg, device=0) as eng:
+        eng.load_weights(weights, fold_tail=False)
+        up = [o for o in eng.ops() if o["name"].startswith("Up-PS")]
+        assert up and up[0]["kernel"] == "conv3_h" and up[0]["out_channels"] == 9, up
+        y1 = eng.forward(x, x2)
+        eng.set_option("split16", 0)
+        up = [o for o in eng.ops() if o["name"].startswith("Up-PS")]
+        assert up[0]["kernel"] == "conv_igemm", up
+        y0 = eng.forward(x, x2)
+    assert float(np.max(np.abs(y1 - ref))) <= MAX_ABS_TOL and float(np.max(np.abs(y0 - ref))) <= MAX_ABS_TOL
 
 
 def test_p16_overflow_recomputes_the_image_on_the_float32_plan(oracle):
