@@ -52,6 +52,51 @@ __global__ __launch_bounds__(512, 2) void probe(const h8* src, float* out, int i
     out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y + s.z + s.w;
 }
 
+// The same tap (96 channels x 64 pixels x K = 32 x 3 products) on v_mfma_f32_32x32x16_f16: 3 channel tiles x 2 pixel tiles x 2 K halves x 3
+// products = 36 instructions of twice the work, 12 A + 8 B fragments, 6 x 16 accumulator registers -- half the operand reads per MAC.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(512, 2) void probe32(const h8* src, float* out, int iters) {
+    h8 wh[3][2], wl[3][2], xh[2][2], xl[2][2];
+    const h8* p = src + threadIdx.x % 64;
+    for (int n = 0; n < 3; ++n) for (int k = 0; k < 2; ++k) { wh[n][k] = p[(4 * n + 2 * k) * 64]; wl[n][k] = p[(4 * n + 2 * k + 1) * 64]; }
+    for (int m = 0; m < 2; ++m) for (int k = 0; k < 2; ++k) { xh[m][k] = p[(12 + 4 * m + 2 * k) * 64]; xl[m][k] = p[(12 + 4 * m + 2 * k + 1) * 64]; }
+    f32x16 acc[3][2];
+    for (int n = 0; n < 3; ++n) for (int m = 0; m < 2; ++m) for (int i = 0; i < 16; ++i) acc[n][m][i] = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[n][k], xh[m][k], acc[n][m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n][k], xl[m][k], acc[n][m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n][k], xh[m][k], acc[n][m], 0, 0, 0);
+            }
+        for (int n = 0; n < 3; ++n) for (int k = 0; k < 2; ++k) asm volatile("" : "+v"(wh[n][k]), "+v"(wl[n][k]));
+        for (int m = 0; m < 2; ++m) for (int k = 0; k < 2; ++k) asm volatile("" : "+v"(xh[m][k]), "+v"(xl[m][k]));
+    }
+    float s = 0.0f;
+    for (int n = 0; n < 3; ++n) for (int m = 0; m < 2; ++m) for (int i = 0; i < 16; ++i) s += acc[n][m][i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+static void run32(int threads, const h8* src, float* out) {
+    const int blocks = 256, iters = 300;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    probe32<<<blocks, threads>>>(src, out, 10);
+    float best = 1e30f;
+    for (int r = 0; r < 3; ++r) {
+        hipEventRecord(e0); probe32<<<blocks, threads>>>(src, out, iters); hipEventRecord(e1); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    const int wps = threads / 256;
+    const double eq = (double)iters * 72 * wps;                 // in 16x16x32 instructions of the same work
+    printf("32x32x16, same tap      %d wave(s)/SIMD: %.3f ms  -> %.2f ns per 16x16x32-equivalent MFMA per SIMD\n", wps, best, best * 1e6 / eq);
+}
+
 template <int NT, int ORDER>
 static void run(int threads, const h8* src, float* out) {
     const int blocks = 256, iters = 300;
@@ -77,7 +122,7 @@ int main() {
     hipMalloc(&src, n * 16); hipMalloc(&out, 256 * 512 * 4);
     hipMemcpy(src, h.data(), n * 16, hipMemcpyHostToDevice);
     for (int t : {256, 512}) {
-        run<6, 2>(t, src, out); run<6, 0>(t, src, out); run<6, 1>(t, src, out);
+        run<6, 2>(t, src, out); run<6, 0>(t, src, out); run<6, 1>(t, src, out); run32(t, src, out);
         run<3, 0>(t, src, out); run<3, 1>(t, src, out);      // (these overflow to inf: MFMAs on non-finite accumulators take 50x longer)
     }
     return 0;
