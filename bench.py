@@ -53,9 +53,18 @@ SUSTAINED_F16_MFMA_TFLOPS = 2100.0   # measured (tools/mfma_two_waves.hip): 1024
 PEAK_HBM_GBS = 8000.0
 
 
-def _pmc_file(prefix):
+def _kernel_family(name):
+    """Kernel family of a profiler kernel name ('void dcscn::conv3_h8<6, 5, ...>(...)' / 'conv3_h8<6,5,0,6,true>') or of a
+    dcscn_op_info kernel: the bare identifier in front of the template arguments."""
+    n = name.split("(")[0].split("<")[0].strip()
+    return n.split("::")[-1].split(" ")[-1]
+
+
+def _pmc_file(prefix, run_kernels=None):
     """Latest committed PMC summary of the bench command in which kernels named ``prefix``... did real work (in a split16
-    profile the conv_wino2 / conv_nin launches are the empty fallbacks behind the f16 kernels)."""
+    profile the conv_wino2 / conv_nin launches are the empty fallbacks behind the f16 kernels).  ``run_kernels``: the kernel
+    families dcscn_op_info reports for THIS run; a file whose working kernels are a different set was taken on other kernels
+    (a kernel changed and tools/rocprof_bench.sh was not re-run) and is refused -- returns (None, "stale: ...")."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_per_dispatch.json")), reverse=True):
         try:
@@ -64,22 +73,48 @@ def _pmc_file(prefix):
         except (OSError, KeyError, ValueError):
             continue
         if any(n.startswith(prefix) and k.get("avg_duration_ns_profiled", 0) > 1e5 for n, k in kernels.items()):
-            return path
-    return None
+            if run_kernels is not None:
+                # the kernels that did real work under the profiler (the gated float32 plan's launches exit at once: < 20 us)
+                worked = {_kernel_family(n) for n, k in kernels.items() if k.get("avg_duration_ns_profiled", 0) > 2e4}
+                worked -= PMC_IGNORED_KERNELS
+                want = set(run_kernels) - PMC_IGNORED_KERNELS
+                if worked != want:
+                    return None, "stale: %s was taken on kernels %s, this run launches %s" % (
+                        os.path.basename(path), sorted(worked), sorted(want))
+            return path, None
+    return None, "no committed PMC file for kernels named %s*" % prefix
+
+
+# helper kernels that are not launches of the plan (dcscn_op_info does not list them)
+PMC_IGNORED_KERNELS = {"pass_begin_kernel", "fill_kernel", "p16_pack_kernel", "p16_unpack_kernel"}
 
 
 DOM_PREFIX = ["conv3_h"]      # kernel-name prefix of the dominant launches in the PMC file (set from the run: conv3_h / conv_wino)
 
 
-def pmc_replay(dom_ms, nin_ms, algorithmic_bytes):
+def csrc_digest():
+    """sha256 over the kernel sources (csrc/*, sorted): written into the PMC summary by tools/summarize_rocprof.py and compared
+    here, so that a replayed counter can be told from one taken on this very build."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "dcscn-super-resolution_amd", "csrc", "*"))):
+        if os.path.isfile(path):
+            h.update(os.path.basename(path).encode())
+            with open(path, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def pmc_replay(dom_ms, nin_ms, algorithmic_bytes, run_kernels=None):
     """REPLAYED (not measured in this run): figures from the committed rocprofv3 PMC passes of this same command
     (tools/rocprof_bench.sh -> profiles/r*_pmc_per_dispatch.json), combined with this run's kernel times.
     Returns (traffic, north_star).  traffic: HBM bytes per step of the dominant kernel, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950 (the counter tallies 128-B requests at
     64 B), WRITE_SIZE as reported."""
-    path = _pmc_file(DOM_PREFIX[0])
+    path, why = _pmc_file(DOM_PREFIX[0], run_kernels)
     if not path:
-        return None, None
+        return None, {"replayed": False, "traffic": None, "reason": why}
     try:
         with open(path) as f:
             doc = json.load(f)
@@ -99,6 +134,11 @@ def pmc_replay(dom_ms, nin_ms, algorithmic_bytes):
                        "algorithmic_bytes_per_step": algorithmic_bytes,
                        "traffic_ratio": round(corrected / algorithmic_bytes, 3) if algorithmic_bytes else None}
         ns = {"replayed": True, "source": os.path.basename(path)}
+        # counters taken on exactly this build of csrc/ ?  (None: the file predates the digest)
+        same_build = (doc["csrc_sha256"] == csrc_digest()) if "csrc_sha256" in doc else None
+        ns["counters_taken_on_this_build_of_csrc"] = same_build
+        if traffic:
+            traffic["counters_taken_on_this_build_of_csrc"] = same_build
         if traffic and dom_ms > 0:
             gbs = traffic["bytes_per_step"] / (dom_ms * 1e-3) / 1e9
             alg_gbs = algorithmic_bytes / (dom_ms * 1e-3) / 1e9
@@ -131,6 +171,164 @@ def pmc_replay(dom_ms, nin_ms, algorithmic_bytes):
         return None, None
 
 
+L7_FLAGS = dict(layers=7, filters=32, min_filters=8, filters_decay_gamma=1.2, nin_filters=24, nin_filters2=8,
+                reconstruct_layers=0, pixel_shuffler_filters=1)
+# the other single-GPU configurations of BASELINE.json ("also C2, C5"), timed beside the headline at N = 1
+OTHER_CONFIGS = {
+    "C2": ("dcscn_L8_F96to48 x2 forward, 256 48x48 Y patches (BASELINE.json configs[1])", dict(layers=8, filters=96), 256),
+    "C5": ("dcscn_L7_F32to8 x4 depthwise-separable forward, 1024 48x48 Y patches (BASELINE.json configs[4])",
+           dict(L7_FLAGS, scale=4, depthwise_separable=True), 1024),
+}
+PEAK_F32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 32 FMA lanes per clock and SIMD (a wave64 instruction issues over 2 cycles)
+C3H_KERNELS = ("conv3_h", "conv3_h8", "conv3_h2")
+
+
+def narrow_net_work(O, cfg):
+    """Per LR pixel, from the reference's graph (oracle.build_topology = DCSCN.py:222-325): MACs of the depthwise halves of
+    separable convs (VALU work: no contraction over channels), MACs of everything else (matrix work), values entering a
+    contraction (each is split into an f16 (hi, lo) pair: 1.5 VALU operations) and values leaving one (scale, PReLU: 3)."""
+    res = {"x": 1, "x2": cfg["scale"]}
+    dw = mm = vin = vout = 0
+    for op in O.build_topology(cfg):
+        kind = op["op"]
+        if kind == "conv":
+            r = res[op["src"]]
+            res[op["dst"]] = r
+            px = r * r
+            k2 = op["k"] * op["k"]
+            if op["ds"] and op["k"] > 1:
+                dw += px * k2 * op["cin"]
+                mm += px * op["cin"] * op["cout"]
+            else:
+                mm += px * k2 * op["cin"] * op["cout"]
+            vin += px * op["cin"]
+            vout += px * op["cout"]
+        elif kind == "concat":
+            res[op["dst"]] = res[op["srcs"][0]]
+        elif kind == "depth_to_space":
+            res[op["dst"]] = res[op["src"]] * op["block"]
+        elif kind == "conv_transpose":
+            res[op["dst"]] = res[op["src"]] * op["scale"]
+        elif "dst" in op:
+            res[op["dst"]] = res.get(op.get("src"), cfg["scale"])
+    return {"depthwise_macs": dw, "matrix_macs": mm, "values_in": vin, "values_out": vout}
+
+
+def time_other_config(engine, O, torch, key, steps, warmup, device_index, stream):
+    """One more BASELINE configuration, timed like the headline (inputs resident in HBM, y left in HBM, barrier-free at N = 1:
+    synchronize on both sides of exactly `steps` forwards) with the per-launch HIP-event profile of the same steps."""
+    name, flags, n = OTHER_CONFIGS[key]
+    cfg = O.make_config(**flags)
+    eng = engine.Engine(cfg, device=device_index)
+    try:
+        eng.load_weights(O.synthetic_weights(cfg, seed=0))
+        s = cfg["scale"]
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(4321)
+        x = torch.rand((n, PATCH, PATCH, 1), device="cuda", generator=gen) * 255.0
+        x2 = torch.rand((n, PATCH * s, PATCH * s, 1), device="cuda", generator=gen) * 255.0
+        y = torch.empty_like(x2)
+        torch.cuda.synchronize()
+
+        def fwd():
+            eng.forward_device(x.data_ptr(), x2.data_ptr(), y.data_ptr(), n, PATCH, PATCH, stream)
+        for _ in range(max(warmup, 3)):
+            fwd()
+        eng.set_option("profile", 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fwd()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        per_op = eng.profile(with_float32_plan=True)
+        f32_plan_ms = per_op.pop()
+        eng.set_option("profile", 0)
+        if not bool(torch.isfinite(y).all().item()):
+            raise RuntimeError("non-finite output")
+        ops = eng.ops()
+        px = n * PATCH * PATCH
+        ms = el / steps * 1e3
+        out = {"workload": name, "ms_per_step": round(ms, 4), "value": round(px / (ms * 1e-3) / 1e6, 3), "unit": "LR Mpix/s",
+               "steps": steps, "kernel_ms_per_step": round(sum(per_op), 4), "float32_plan_gated_ms": round(f32_plan_ms, 4),
+               "launches": [{"name": o["name"], "kernel": o["kernel"], "ms": round(m, 4)} for o, m in zip(ops, per_op)]}
+        dom = [(o, m) for o, m in zip(ops, per_op) if o["kernel"] in C3H_KERNELS and o["kernel_size"] == 3 and o["out_channels"] > 1]
+        if dom:
+            # the headline's accounting: f16 FLOPs the 3x3 launches issue (3 products per MAC, channel padding included) per second of
+            # their own launch time against the dense f16 MFMA peak; useful = 3 x the algorithmic FLOPs; algorithmic = SURVEY 8(d)
+            dms = sum(m for _, m in dom)
+            ex = sum(2.0 * o["executed_macs_per_lr_pixel"] for o, _ in dom) * px
+            alg = sum(2.0 * o["macs_per_lr_pixel"] for o, _ in dom) * px
+            out["roofline"] = {"kernel": "+".join(sorted({o["kernel"] for o, _ in dom})) + " 3x3, %d launches/pass" % len(dom), "bound": "mfma",
+                               "achieved": round(ex / (dms * 1e-3) / 1e12, 3), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ex / (dms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                               "useful_frac": round(3.0 * alg / (dms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                               "algorithmic_frac": round(alg / (dms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                               "kernel_ms_per_step": round(dms, 4), "traffic": None}
+        else:
+            # streamed narrow net: nothing but x, x2 and y has to touch HBM -- 4 + 4 s^2 + 4 s^2 bytes per LR pixel
+            io = 4.0 * (1 + 2 * s * s)
+            w = narrow_net_work(O, cfg)
+            t_hbm = io * px / (PEAK_HBM_GBS * 1e9) * 1e3
+            t_mfma = 3.0 * 2.0 * w["matrix_macs"] * px / (PEAK_F16_MFMA_TFLOPS * 1e12) * 1e3
+            valu_ops = w["depthwise_macs"] + 1.5 * w["values_in"] + 3.0 * w["values_out"]
+            t_valu = valu_ops * px / (PEAK_F32_VALU_TFLOPS / 2.0 * 1e12) * 1e3
+            out["roofline"] = {"kernel": "+".join(o["kernel"] for o in ops), "bound": "hbm",
+                               "achieved": round(io * px / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(io * px / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                               "compulsory_bytes_per_lr_pixel": io,
+                               "floor_ms": {"hbm": round(t_hbm, 4), "mfma_3_products": round(t_mfma, 4), "valu": round(t_valu, 4),
+                                            "valu_plus_mfma": round(t_valu + t_mfma, 4)},
+                               "frac_of_floor": round(max(t_hbm, t_valu + t_mfma) / ms, 4),
+                               "work_per_lr_pixel": w,
+                               "note": "achieved = compulsory I/O (x, x2, y: %d B per LR pixel) over the step; the floor is not HBM but the "
+                                       "arithmetic: depthwise MACs + 1.5 per split input value + 3 per output value on the VALU at the "
+                                       "spec rate (32 lanes per clock and SIMD, no packed f32) plus three f16 products per matrix MAC at "
+                                       "the dense f16 peak, without counting any overlap between the two pipes" % int(io)}
+        return out
+    finally:
+        eng.close()
+
+
+def parity_leg():
+    """The second half of BASELINE's metric, computed in this run: the shipped c-DCSCN x2 checkpoint (tests/golden/weights_L7_x2.npz,
+    the reference's trained weights) on the five Set5 images through model.do_for_evaluate (DCSCN.py:672-703) -- PSNR per image against
+    the float64 oracle's (tests/golden/goldens.json, written by tests/golden/make_golden.py) -- and the 48x48 crop vector's max-abs
+    error against the oracle's float64 output.  Fixtures only: nothing under oracle/ runs here."""
+    import tempfile
+    from dcscn_amd.model import SuperResolution
+    from helper import args as hargs
+    golden = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(golden, "goldens.json")) as f:
+        g = json.load(f)
+
+    class _F(dict):
+        __getattr__ = dict.__getitem__
+    d = {n: hargs.FLAGS._flags[n].default for n in hargs.FLAGS}
+    d.update(g["models"]["L7_x2"]["flags"])
+    d.pop("legacy_no_c", None)
+    with tempfile.TemporaryDirectory() as tmp:
+        d.update(checkpoint_dir=os.path.join(tmp, "models"), self_ensemble=1, log_filename="")
+        m = SuperResolution(_F(d))
+        m.build_graph()
+        m.init_all_variables()
+        m.load_weights(dict(np.load(os.path.join(golden, "weights_L7_x2.npz"))))
+        try:
+            psnr = [m.do_for_evaluate(os.path.join(golden, "set5", f))[0] for f in g["files"]]
+            crop = np.load(os.path.join(golden, "crop_L7_x2.npz"))
+            out = m.do(crop["lr"], crop["bicubic"])
+        finally:
+            m.close()
+    want = g["models"]["L7_x2"]["set5_psnr"]
+    return {"set5_psnr_delta_db": float(max(abs(a - b) for a, b in zip(psnr, want))),
+            "set5_psnr_mean_db": round(float(np.mean(psnr)), 4), "set5_psnr_mean_oracle_db": round(float(g["models"]["L7_x2"]["set5_mean"]), 4),
+            "max_abs": float(np.max(np.abs(out - crop["output"]))),
+            "bars": {"set5_psnr_delta_db": 1e-3, "max_abs": 1e-4},
+            "model": "dcscn_L7_F32to8 x2 (c-DCSCN): the reference's shipped trained checkpoint -- the L12 / L8 blobs are not shipped "
+                     "(.MISSING_LARGE_BLOBS), so the headline topology has no trained-weight parity; its synthetic-weight parity is tests/test_hip_parity.py",
+            "against": "float64 oracle values committed under tests/golden (make_golden.py); README.md's published 37.15 dB is reproduced by them"}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +346,8 @@ def parse_args():
     ap.add_argument("--layer-by-layer", action="store_true",
                     help="headline on the reference's layers one by one (fold_linear_tail = 0) instead of the library default")
     ap.add_argument("--no-split16", action="store_true", help="headline on the pure f32 kernels (split16 = 0: conv_wino2 / conv_nin)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2 / C5 legs (other_configs) and the Set5 parity leg")
+    ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each other_configs leg")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the extra strong-scaling leg (1024 patches in total)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --patches is the GLOBAL batch, split into contiguous shards over the ranks")
@@ -305,7 +505,7 @@ def main():
         lr_pixels = n * PATCH * PATCH                         # this rank's
         global_lr_pixels = global_patches * PATCH * PATCH
         # dominant kernel: the Winograd 3x3 launches (CNN2..12, B2, and Up-PS in the layer-by-layer graph)
-        C3H = ("conv3_h", "conv3_h8")           # the split16 3x3 kernels: 4-wave workgroups / persistent 8-wave workgroups sharing the input tile
+        C3H = C3H_KERNELS                       # the split16 3x3 kernels: 4-wave workgroups / persistent 8-wave workgroups sharing the input tile
         dom = [(o, ms) for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_wino2") + C3H
                and o["kernel_size"] == 3 and o["out_channels"] > 1]
         dom_kernels = sorted({o["kernel"] for o, _ in dom})
@@ -339,7 +539,7 @@ def main():
                          fx / (ms * 1e-3) / 1e12 if ms else 0, by / (ms * 1e-3) / 1e9 if ms else 0), file=sys.stderr)
         nin_ms = sum(ms for o, ms in zip(ops, per_op_ms) if o["kernel"] in ("conv_igemm", "conv_nin", "conv_nin_h") and o["kernel_size"] == 1)
         full_workload = n == PATCHES_PER_GPU and not args.no_winograd
-        traffic, north_star = pmc_replay(dom_ms, nin_ms, dom_bytes) if full_workload else (None, None)
+        traffic, north_star = pmc_replay(dom_ms, nin_ms, dom_bytes, {o["kernel"] for o in ops}) if full_workload else (None, None)
         graph = ("linear tail (Up-PS conv + depth_to_space + R-CNN1) folded into one 5x5 conv -- library default, include/dcscn.h fold_linear_tail"
                  if folded else "the reference's layers, one launch per layer (B1+A1 share a launch)")
         result = {
@@ -379,7 +579,8 @@ def main():
                 "algorithmic_frac": round(algorithmic / dom_peak, 4),
                 "frac_of_sustained": round(executed / SUSTAINED_F16_MFMA_TFLOPS, 4) if on_f16 else None,
                 "traffic": traffic["bytes_per_step"] if traffic else None,
-                "traffic_detail": traffic,
+                "traffic_detail": traffic if traffic else ({"traffic": None, "reason": north_star["reason"]}
+                                                           if north_star and "reason" in north_star else None),
                 "executed_flop_per_step": dom_exec,
                 "algorithmic_flop_per_step": dom_flop,
                 "vs_f32_peak": {"algorithmic_tflops": round(algorithmic, 3), "peak": PEAK_F32_MFMA_TFLOPS,
@@ -552,6 +753,18 @@ def main():
                 eng2.close()
             except Exception as exc:      # the headline line must survive a failure of the extra leg
                 result["layer_by_layer"] = {"error": str(exc)}
+        if world == 1 and not args.no_other_configs and not args.no_extra_graph:
+            # SURVEY.md 8(d) "also C2, C5": the other single-GPU BASELINE configurations, and the metric's "PSNR delta vs ref on Set5"
+            result["other_configs"] = {}
+            for key in OTHER_CONFIGS:
+                try:
+                    result["other_configs"][key] = time_other_config(engine, O, torch, key, args.other_steps, args.warmup, device_index, stream)
+                except Exception as exc:
+                    result["other_configs"][key] = {"error": str(exc)}
+            try:
+                result["parity"] = parity_leg()
+            except Exception as exc:
+                result["parity"] = {"error": str(exc)}
         print(json.dumps(result), flush=True)
 
     eng.close()

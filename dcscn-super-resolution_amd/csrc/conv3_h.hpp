@@ -180,7 +180,7 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
                 const int kq = ((cq >> 1) - (hcol >> 1)) & 3;  // the unit c3h_unit puts at slot cq of this halo column
                 const int part = (cq ^ kq ^ hcol) & 1;
                 const bool ok = ((ok_mask >> r) & 1u) && kq < rem;
-                const unsigned off = ok ? (unsigned)(128 + (pix0 + hrow * W + hcol) * rec + (2 * kq + part) * 16) : (unsigned)(cq * 16);
+                const unsigned off = ok ? 128u + (unsigned)(pix0 + hrow * W + hcol) * (unsigned)rec + (unsigned)((2 * kq + part) * 16) : (unsigned)(cq * 16);
                 gin[r] = *reinterpret_cast<const f32x4*>(base + (size_t)off);
                 hcol += 32 - G::HT; hrow += 1;
                 if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }
@@ -597,11 +597,11 @@ __device__ __forceinline__ void conv3_h_body(const ConvArgs& a, char* smem, int 
                 }
                 const bool row_ok = !MASK || y0 + 4 * wave + m < H;
                 if (o16) {
-                    if constexpr (ACT_C < 0) chk = nonfinite_acc(chk, acc[m][n], zero);   // (a saturating activator hides a non-finite accumulator)
-                    const u32x4 unit = p16_unit(v, m1, chk, zero2);
+                    if constexpr (ACT_C < 0) { if (chan_ok && row_ok) chk = nonfinite_acc(chk, acc[m][n], zero); }   // (a saturating activator hides a non-finite accumulator)
+                    const u32x4 unit = p16_unit(v, m1, chk, zero2, chan_ok && row_ok);
                     if (chan_ok && row_ok) *reinterpret_cast<u32x4*>(base + (size_t)(voff + m * rowb)) = unit;
                 } else {
-                    chk = nonfinite_acc(chk, acc[m][n], zero);
+                    if (chan_ok && row_ok) chk = nonfinite_acc(chk, acc[m][n], zero);
                     if (chan_ok && row_ok) *reinterpret_cast<f32x4*>(base + (size_t)(voff + m * rowb)) = v;
                 }
             });

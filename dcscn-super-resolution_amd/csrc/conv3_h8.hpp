@@ -243,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
         const int kq = ((s >> 1) - (hcol >> 1)) & 3;
         const int part = (s ^ kq ^ hcol) & 1;
         const bool ok = ((mask >> r) & 1u) && kq < rem;
-        const unsigned voff = ok ? (unsigned)(128 + (pix0 + hrow * W + hcol) * rec + (2 * kq + part) * 16) : (unsigned)(s * 16);
+        const unsigned voff = ok ? 128u + (unsigned)(pix0 + hrow * W + hcol) * (unsigned)rec + (unsigned)((2 * kq + part) * 16) : (unsigned)(s * 16);
         const int piece = r < L - 1 ? wave + 8 * r : 40;
         if constexpr (C3E_ABL & 2) return;
         glds16c(base, voff, lds0 + (unsigned)(buf * G::IN_BUF + piece * 1024));
@@ -354,13 +354,13 @@ __global__ __launch_bounds__(512, 2) void conv3_h8(const ConvArgs a) {
                             v.z = v.z > 0.0f ? v.z : av.z * v.z;
                             v.w = v.w > 0.0f ? v.w : av.w * v.w;
                         } else if constexpr (ACT_C < 0) {
-                            chk = nonfinite_acc(chk, acc[m][n], zero);     // (a saturating activator hides a non-finite accumulator)
+                            if (chan_ok && (!MASK || e_y0 + 4 * w4 + m < H)) chk = nonfinite_acc(chk, acc[m][n], zero);     // (a saturating activator hides a non-finite accumulator)
                             v.x = activate1(v.x, av.x, a.act);
                             v.y = activate1(v.y, av.y, a.act);
                             v.z = activate1(v.z, av.z, a.act);
                             v.w = activate1(v.w, av.w, a.act);
                         }
-                        const u32x4 unit = p16_unit(v, m1, chk, zero2);
+                        const u32x4 unit = p16_unit(v, m1, chk, zero2, chan_ok && (!MASK || e_y0 + 4 * w4 + m < H));
                         if (chan_ok && (!MASK || e_y0 + 4 * w4 + m < H)) *reinterpret_cast<u32x4*>(base + (size_t)(voff + m * rowb)) = unit;
                     });
                 });

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
                 const int kq = ((cq >> 1) - (hcol >> 1)) & 3;  // the unit c3h_unit puts at slot cq of this halo column
                 const int part = (cq ^ kq ^ hcol) & 1;
                 const bool ok = ((ok_mask >> r) & 1u) && kq < rem;
-                const unsigned off = ok ? (unsigned)(128 + (pix0 + hrow * W + hcol) * rec + (2 * kq + part) * 16) : (unsigned)(cq * 16);
+                const unsigned off = ok ? 128u + (unsigned)(pix0 + hrow * W + hcol) * (unsigned)rec + (unsigned)((2 * kq + part) * 16) : (unsigned)(cq * 16);
                 gin[r] = *reinterpret_cast<const f32x4*>(base + (size_t)off);
                 hcol += 32 - G::HT; hrow += 1;
                 if (hcol >= G::HT) { hcol -= G::HT; hrow += 1; }

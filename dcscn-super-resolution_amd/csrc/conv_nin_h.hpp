@@ -240,8 +240,8 @@ __device__ __forceinline__ void conv_nin_h_body(const ConvArgs& a, float* smem, 
                     v.y = activate1(v.y, av.y, act_e);
                     v.z = activate1(v.z, av.z, act_e);
                     v.w = activate1(v.w, av.w, act_e);
-                    if (ACT_C < 0) chk[m] = nonfinite_acc(chk[m], acc[m][n], zero);
-                    const u32x4 unit = p16_unit(v, m1, chk[m], zero2);
+                    if (ACT_C < 0 && p < npix && chan_ok) chk[m] = nonfinite_acc(chk[m], acc[m][n], zero);
+                    const u32x4 unit = p16_unit(v, m1, chk[m], zero2, p < npix && chan_ok);
                     if (p < npix && chan_ok && (!(NINH_ABL & 4) || unit.x == 0x12345u)) *reinterpret_cast<u32x4*>(base + (size_t)p * rec) = unit;
                 });
             } else if (cc < owidth) {

@@ -428,11 +428,20 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t per_image = (int64_t)H * W;
     int64_t ws_per_lr_pixel = 0;      // workspace bytes per LR pixel
-    for (const WsBuf& b : h->bufs) ws_per_lr_pixel += (int64_t)b.res * b.res * b.stride * (int64_t)sizeof(float);
+    // a P16 tensor (p16.hpp) is carved at max(float32 bytes, P16 bytes): its last chunk's record is padded to whole 32-byte octet pairs, so
+    // a tensor whose stride is 4 mod 8 is larger than its float32 form (the budget is the hard knob, count what is carved; the
+    // per-plane zero records and 256-byte roundings are the slack of 1 / 64 below)
+    const bool want16 = p16_active(h);
+    for (const WsBuf& b : h->bufs) {
+        int64_t per_pixel = (int64_t)b.stride * (int64_t)sizeof(float);
+        if (want16 && b.p16_ok && b.stride > 0) per_pixel = std::max<int64_t>(per_pixel, 128 * (b.octs / 4) + 32 * (b.octs % 4));
+        ws_per_lr_pixel += (int64_t)b.res * b.res * per_pixel;
+    }
+    ws_per_lr_pixel += (ws_per_lr_pixel + 63) / 64;
     int64_t pass_pixels = std::min<int64_t>(h->sub_batch_pixels, h->workspace_budget / std::max<int64_t>(ws_per_lr_pixel, 1));
     // sub_batch_pixels is a soft knob (a pass holds at least one image); the workspace budget is the hard one
     int64_t budget_pixels = h->workspace_budget / std::max<int64_t>(ws_per_lr_pixel, 1);
-    if (p16_active(h)) {
+    if (want16) {
         // record offsets inside a P16 plane are 32-bit (kernels.h: kP16MaxPixels): bounds the pixels of a pass at the tensors' resolution
         const int64_t cap = kP16MaxPixels / ((int64_t)h->p16_max_res * h->p16_max_res);
         pass_pixels = std::min(pass_pixels, cap);

@@ -48,6 +48,16 @@ __device__ __forceinline__ u32x4 p16_unit(const f32x4 v, float m1, float& chk, h
     return u32x4{s0.x, s1.x, s0.y, s1.y};
 }
 
+// The same for a lane whose value may lie outside the tensor (a pixel row / column past the image edge, a channel octet past the last):
+// such a lane takes part in the swap but must not raise the image's redo flag -- the float32-tensor epilogues only check what they store
+// (ADVICE r05), and "a flagged image equals its split16 = 0 run, every other image keeps its bits" needs the same rule here.
+__device__ __forceinline__ u32x4 p16_unit(const f32x4 v, float m1, float& chk, h2 zero2, bool live) {
+    float c = chk;
+    const u32x4 unit = p16_unit(v, m1, c, zero2);
+    chk = live ? c : chk;
+    return unit;
+}
+
 // float32 NHWC -> P16 (tests, the harness, and tensors a float32 kernel produced for a split16 consumer); one thread per (pixel, octet)
 static __global__ void p16_pack_kernel(const float* in, int in_stride, int channels, long long npix, P16Desc d) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;

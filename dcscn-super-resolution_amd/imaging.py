@@ -110,6 +110,7 @@ def load_image(filename, width=0, height=0, channels=0, alignment=0, print_conso
 # are on disk unless it runs inside `deferred_saves()` (evaluate.py: the whole data set is one batch of writes).
 _save_pool = None
 _save_pending = []
+_save_failed = []             # writes that failed while save_image was only waiting for room: raised by flush_saves
 _save_defer = 0
 _SAVE_MAX_PENDING = 64        # images in flight: a fast device path must not pile up uint8 copies faster than they are encoded
 
@@ -137,8 +138,10 @@ def save_image(filename, image, print_console=True):
         if _save_pool is None:
             from concurrent.futures import ThreadPoolExecutor
             _save_pool = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
-        while len(_save_pending) >= _SAVE_MAX_PENDING:      # back-pressure: wait for the oldest write (its error, if any, surfaces here)
-            _save_pending.pop(0).result()
+        while len(_save_pending) >= _SAVE_MAX_PENDING:      # back-pressure: wait for the oldest write
+            oldest = _save_pending.pop(0)
+            if oldest.exception() is not None:              # (waits) a failed write is reported by flush_saves at the block's
+                _save_failed.append(oldest)                 # exit, not from inside this unrelated call
         _save_pending.append(_save_pool.submit(_encode_and_write, filename, image, mode))
     else:
         _encode_and_write(filename, image, mode)
@@ -148,9 +151,15 @@ def save_image(filename, image, print_console=True):
 
 def flush_saves():
     """Wait until every image handed to save_image inside a deferred_saves() block is on disk (re-raises the first write error)."""
-    pending, _save_pending[:] = list(_save_pending), []
-    for f in pending:
-        f.result()
+    pending, _save_pending[:] = _save_failed + list(_save_pending), []
+    _save_failed[:] = []
+    first = None
+    for f in pending:                                       # wait for ALL of them, then raise the first error
+        err = f.exception()
+        if err is not None and first is None:
+            first = err
+    if first is not None:
+        raise first
 
 
 class deferred_saves(object):
@@ -169,6 +178,8 @@ class deferred_saves(object):
             except Exception:
                 if exc_type is None:                          # (an exception from the block itself wins over a write error)
                     raise
+                # ... but the write error is not lost: it goes to the log
+                logging.exception("an image write failed while the block was already unwinding from %s", exc_type.__name__)
         return False
 
 

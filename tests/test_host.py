@@ -292,6 +292,27 @@ def test_no_cpu_fallback():
     assert "oracle" not in src
 
 
+def test_batch_norm_is_refused_not_ignored(tmp_path):
+    """--batch_norm=true (tf_graph.py:112-113, 175) is in no shipped model and not implemented; the library must say so
+    (DCSCN_ERR_UNSUPPORTED from dcscn_create, before it even looks for a device) instead of silently running the graph without it --
+    through the C ABI and through the reference-shaped model class (whose name still gets the reference's _BN suffix, DCSCN.py:131)."""
+    from dcscn_amd import engine
+    from dcscn_amd.model import SuperResolution
+    with pytest.raises(engine.EngineError) as e:
+        engine.Engine(dict(batch_norm=True))
+    assert e.value.status == 2 and engine.STATUS_NAMES[2] == "UNSUPPORTED" and "batch_norm" in str(e.value)
+    m = SuperResolution(_flags(batch_norm=True, checkpoint_dir=str(tmp_path / "models")))
+    assert m.name.endswith("_BN_R1F32")
+    with pytest.raises(engine.EngineError) as e:
+        m.build_graph()
+    assert e.value.status == 2
+    # the other flags the survey marks unsupported are refused the same way, not approximated
+    for bad in (dict(channels=3), dict(cnn_size=4), dict(scale=5)):
+        with pytest.raises(engine.EngineError) as e:
+            engine.Engine(bad)
+        assert e.value.status == 2, bad
+
+
 def test_resample_tables_reproduce_pillow():
     """The library's per-axis bicubic tables (host code, no GPU), applied in float64 in tap order with one rounding
     per pass, must give Pillow's mode-'F' BICUBIC resize bit for bit -- the same tables drive the device kernels

@@ -54,8 +54,11 @@ def main(src, dst, tag):
             out[k] = {"dispatches": calls[k], "forwards": 4, "avg_duration_ns_profiled": dur[k] / n}
             out[k].update({c: v / n for c, v in pmc[k].items()})
         with open(os.path.join(dst, "%s_pmc_per_dispatch.json" % tag), "w") as f:
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench                                      # csrc_digest: bench.py compares it with the build it runs on
             json.dump({"note": "per-dispatch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported (uncalibrated, "
                                "see MI355X_MICROARCH.md HBM section); SQ_* summed over the chip",
+                       "csrc_sha256": bench.csrc_digest(),
                        "kernels": out}, f, indent=1, sort_keys=True)
 
 
