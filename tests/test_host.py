@@ -359,6 +359,50 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(d["value"] - 1024 * 48 * 48 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
 
 
+def test_committed_r06_bench_line_carries_the_other_configs_and_the_parity_half():
+    """profiles/r06_bench_n1.json (the line of the r06 tree on an MI355X box): besides the contract fields, BASELINE's other
+    single-GPU configs with their roofline objects ("also C2, C5"), the metric's "PSNR delta vs ref on Set5" computed
+    in the run, and counters replayed only from a PMC file taken on the same kernels."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r06_bench_n1.json")) as f:
+        d = json.load(f)
+    assert d["metric"].startswith("LR Mpixels/sec at 48x48 patches, L12_F196to48 x2") and d["n_gpus"] == 1
+    assert abs(d["value"] - 1024 * 48 * 48 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["useful_frac"] <= r["frac"] <= 1.0
+    assert r["traffic"] is None or r["traffic_detail"]["replayed"] is True
+    for key, bound, px in (("C2", "mfma", 256 * 48 * 48), ("C5", "hbm", 1024 * 48 * 48)):
+        c = d["other_configs"][key]
+        assert "error" not in c and c["steps"] >= 20 and c["unit"] == "LR Mpix/s"
+        assert abs(c["value"] - px / (c["ms_per_step"] * 1e-3) / 1e6) / c["value"] < 1e-3
+        rr = c["roofline"]
+        assert rr["bound"] == bound and 0 < rr["frac"] <= 1.0 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-3
+        assert c["kernel_ms_per_step"] <= c["ms_per_step"]
+    fl = d["other_configs"]["C5"]["roofline"]["floor_ms"]
+    assert fl["valu_plus_mfma"] > fl["hbm"] > 0                 # the narrow net's floor is its arithmetic, not its compulsory I/O
+    par = d["parity"]
+    assert 0 <= par["set5_psnr_delta_db"] <= par["bars"]["set5_psnr_delta_db"] == 1e-3
+    assert 0 <= par["max_abs"] <= par["bars"]["max_abs"] == 1e-4
+
+
+def test_stale_pmc_files_are_refused():
+    """bench.py replays HBM / MFMA counters from the newest committed PMC summary only when the kernels that did real work under
+    the profiler are the kernels of the run ("change a kernel, forget tools/rocprof_bench.sh, and the line quotes
+    stale counters against fresh times")."""
+    import bench
+    run = {"conv_cin1", "conv3_h8", "conv3_h", "conv_nin_h", "conv5_h"}
+    path, why = bench._pmc_file("conv3_h", run)
+    assert path is not None and why is None and os.path.basename(path).startswith("r0")
+    path, why = bench._pmc_file("conv3_h", (run - {"conv3_h"}) | {"conv3_hc"})
+    assert path is None and why.startswith("stale: ")
+    traffic, ns = bench.pmc_replay(15.5, 2.9, 2.3e10, (run - {"conv3_h"}) | {"conv3_hc"})
+    assert traffic is None and ns["traffic"] is None and ns["reason"].startswith("stale: ")
+    assert bench._kernel_family("void dcscn::conv3_h8<6, 5, 0, 6, true>(dcscn::ConvArgs)") == "conv3_h8"
+    assert bench._kernel_family("conv_nin_h<6, 2, 3, 2>") == "conv_nin_h"
+    assert len(bench.csrc_digest()) == 64
+
+
 def test_library_has_no_packed_f32_instructions(tmp_path):
     """v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 return wrong low halves (lanes 48-63) when ANOTHER process's MFMA work shares the
     SIMD (tools/xproc_triage.hip: victim cin1p vs cin1s beside aggressor mfma) -- the r03 cross-process
