@@ -408,6 +408,41 @@ def test_full_size_bench_workload(oracle):
     pick = [0, 1, 511, 512, 1000, 1023]
     ref = oracle.forward(cfg, weights, x[pick], x2[pick], dtype=np.float64)
     assert float(np.max(np.abs(y[pick] - ref))) <= MAX_ABS_TOL
+    # r06 ("the headline config's border / interior mix is pinned on eight patches"): 96 more patches -- every 11th of the
+    # batch, and its last ones -- against the float64 torch-CPU restatement of the same graph (oracle/cpu_path_torch.py, pinned to the
+    # numpy oracle at 1e-9 on these very weights below; oneDNN runs it in seconds where the numpy loops need 4 s per patch)
+    import torch
+    import cpu_path_torch as T
+    model = T.TorchCpuModel(cfg, weights, dtype=torch.float64)
+    assert float(np.max(np.abs(model.forward(x[pick], x2[pick]) - ref))) <= 1e-9
+    more = sorted(set(range(0, n, 11)) | {n - 3, n - 2, n - 1})
+    ref64 = model.forward(x[more], x2[more])
+    err = np.max(np.abs(y[more] - ref64), axis=(1, 2, 3))
+    print("L12 x2 full size: %d patches against float64, worst %.3g, mean of the maxima %.3g" % (len(more), err.max(), err.mean()))
+    assert float(err.max()) <= MAX_ABS_TOL
+
+
+def test_full_size_c2_workload(oracle):
+    """BASELINE.json configs[1] at its full size (L8_F96to48 x2, batch = 256 patches of 48x48): EVERY patch against the float64
+    torch-CPU restatement (pinned to the numpy oracle on three of them), on both kernel families."""
+    import torch
+    import cpu_path_torch as T
+    cfg = oracle.make_config(**CONFIGS["L8_F96to48_x2"])
+    weights = oracle.synthetic_weights(cfg, seed=0)
+    n = 256
+    rng = np.random.default_rng(12)
+    x = rng.uniform(0, 255, (n, 48, 48, 1)).astype(np.float32)
+    x2 = rng.uniform(0, 255, (n, 96, 96, 1)).astype(np.float32)
+    model = T.TorchCpuModel(cfg, weights, dtype=torch.float64)
+    ref = model.forward(x, x2)
+    pick = [0, 100, 255]
+    assert float(np.max(np.abs(oracle.forward(cfg, weights, x[pick], x2[pick], dtype=np.float64) - ref[pick]))) <= 1e-9
+    for split16 in (None, False):
+        with _engine(cfg, weights, split16=split16) as eng:
+            y = eng.forward(x, x2)
+        err = float(np.max(np.abs(y - ref)))
+        print("L8 x2, 256 patches, split16 %s: max-abs %.3g" % (split16, err))
+        assert err <= MAX_ABS_TOL
 
 
 # ---- opt-in graph rewrite: the linear tail as one 5x5 conv (include/dcscn.h "fold_linear_tail") ----------
