@@ -183,6 +183,32 @@ PEAK_F32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 32 FMA lanes per clock and 
 C3H_KERNELS = ("conv3_h", "conv3_h8", "conv3_h2")
 
 
+def other_config_traffic(key, run_kernels, families):
+    """REPLAYED HBM bytes per step of an other_configs leg, from the committed PMC passes of tools/rocprof_other_configs.sh
+    (profiles/r*_<c2|c5>_pmc_per_dispatch.json; FETCH_SIZE x 2 + WRITE_SIZE as for the headline), summed over the kernel
+    `families` (None = every kernel of the pass).  Refused like the headline's when the file was taken on other kernels."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_pmc_per_dispatch.json" % key.lower())), reverse=True):
+        try:
+            with open(path) as f:
+                doc = json.load(f)
+            kernels = doc["kernels"]
+        except (OSError, KeyError, ValueError):
+            continue
+        worked = {_kernel_family(n) for n, k in kernels.items() if k.get("avg_duration_ns_profiled", 0) > 2e4} - PMC_IGNORED_KERNELS
+        if worked != set(run_kernels) - PMC_IGNORED_KERNELS:
+            return None, {"traffic": None, "reason": "stale: %s was taken on kernels %s, this run launches %s" % (
+                os.path.basename(path), sorted(worked), sorted(run_kernels))}
+        total = 0.0
+        for n, k in kernels.items():
+            if (families is None or _kernel_family(n) in families) and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+                total += (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0 * k["dispatches"] / max(k.get("forwards", 6), 1)
+        return total, {"bytes_per_step": total, "replayed": True, "source": os.path.basename(path),
+                       "correction": "FETCH_SIZE x 2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE as reported",
+                       "counters_taken_on_this_build_of_csrc": (doc["csrc_sha256"] == csrc_digest()) if "csrc_sha256" in doc else None}
+    return None, {"traffic": None, "reason": "no committed PMC file for %s" % key}
+
+
 def narrow_net_work(O, cfg):
     """Per LR pixel, from the reference's graph (oracle.build_topology = DCSCN.py:222-325): MACs of the depthwise halves of
     separable convs (VALU work: no contraction over channels), MACs of everything else (matrix work), values entering a
@@ -265,6 +291,13 @@ def time_other_config(engine, O, torch, key, steps, warmup, device_index, stream
                                "useful_frac": round(3.0 * alg / (dms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                                "algorithmic_frac": round(alg / (dms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                                "kernel_ms_per_step": round(dms, 4), "traffic": None}
+            tr, detail = other_config_traffic(key, {o["kernel"] for o in ops}, set(C3H_KERNELS))
+            out["roofline"]["traffic"] = tr
+            out["roofline"]["traffic_detail"] = detail
+            if tr:
+                by = sum(float(o["bytes_per_lr_pixel"]) for o, _ in dom) * px
+                detail["algorithmic_bytes_per_step"] = by
+                detail["traffic_ratio"] = round(tr / by, 3) if by else None
         else:
             # streamed narrow net: nothing but x, x2 and y has to touch HBM -- 4 + 4 s^2 + 4 s^2 bytes per LR pixel
             io = 4.0 * (1 + 2 * s * s)
@@ -285,6 +318,14 @@ def time_other_config(engine, O, torch, key, steps, warmup, device_index, stream
                                        "arithmetic: depthwise MACs + 1.5 per split input value + 3 per output value on the VALU at the "
                                        "spec rate (32 lanes per clock and SIMD, no packed f32) plus three f16 products per matrix MAC at "
                                        "the dense f16 peak, without counting any overlap between the two pipes" % int(io)}
+            tr, detail = other_config_traffic(key, {o["kernel"] for o in ops}, None)
+            out["roofline"]["traffic"] = tr
+            out["roofline"]["traffic_detail"] = detail
+            if tr:
+                detail["compulsory_bytes_per_step"] = io * px
+                detail["traffic_ratio"] = round(tr / (io * px), 3)
+                detail["note"] = ("two launches: Concat2 (32 channels, 128 B per LR pixel) is written by feat_stream and read by tail_stream -- "
+                                  "the counters see exactly x + Concat2 and Concat2 + x2 + y")
         return out
     finally:
         eng.close()

@@ -20,8 +20,9 @@ def main(src, dst, tag):
     if stats:
         rows = [r for r in csv.DictReader(open(stats[0])) if "dcscn::" in r["Name"]]
         with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
-            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline\n")
-            f.write("# (dcscn kernels only; 4 forwards x launches per forward)\n")
+            f.write("# rocprofv3 --kernel-trace --stats -- %s\n" % ("python bench.py --steps 3 --warmup 1 --no-cpu-baseline" if "DCSCN_PROF_FORWARDS" not in os.environ
+                                                                  else "python tools/bench_configs.py --only <config> --steps 3"))
+            f.write("# (dcscn kernels only; %s forwards x launches per forward)\n" % os.environ.get("DCSCN_PROF_FORWARDS", "4"))
             w = csv.writer(f)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
             for r in rows:
@@ -51,7 +52,8 @@ def main(src, dst, tag):
         out = {}
         for k in pmc:
             n = max(calls[k], 1)
-            out[k] = {"dispatches": calls[k], "forwards": 4, "avg_duration_ns_profiled": dur[k] / n}
+            # forwards per profiled run: bench.py --steps 3 --warmup 1 = 4; tools/rocprof_other_configs.sh sets 6 (3 warm-up + 3 timed)
+            out[k] = {"dispatches": calls[k], "forwards": int(os.environ.get("DCSCN_PROF_FORWARDS", "4")), "avg_duration_ns_profiled": dur[k] / n}
             out[k].update({c: v / n for c, v in pmc[k].items()})
         with open(os.path.join(dst, "%s_pmc_per_dispatch.json" % tag), "w") as f:
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
