@@ -280,6 +280,11 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
         h->stream_features = value != 0;
         return DCSCN_OK;
     }
+    if (!strcmp(key, "stream_nin")) {
+        if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the stream_nin option must be set before dcscn_finalize");
+        h->stream_nin = value != 0;
+        return DCSCN_OK;
+    }
     if (!strcmp(key, "stream_dense")) {
         if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the stream_dense option must be set before dcscn_finalize");
         h->stream_dense = value != 0;

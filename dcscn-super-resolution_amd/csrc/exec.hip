@@ -113,7 +113,7 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.x = x;
         a.blob = op.d_w;
         a.N = nb; a.H = H; a.W = W;
-        a.halo = a.L;                                     // receptive-field radius of the fused chain
+        a.halo = a.L + (a.nin.on ? 1 : 0);                // receptive-field radius of the fused chain (B2 behind A1 || B1 adds one)
         if (W <= kStreamPX) { a.n_strips = 1; a.useful_w = W; }
         else { a.useful_w = kStreamPX - 2 * a.halo; a.n_strips = (W + a.useful_w - 1) / a.useful_w; }
         const int64_t cols = (int64_t)nb * a.n_strips;
@@ -124,14 +124,22 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         a.n_jobs = (int)(cols * a.n_blocks);
         a.jobs_per_wg = (a.n_jobs + h->n_cus - 1) / h->n_cus;
         const int grid = (a.n_jobs + a.jobs_per_wg - 1) / a.jobs_per_wg;
-        for (size_t i = 0; i < op.extra_out.size(); ++i) {
-            const int id = op.extra_out[i];
-            S3Out& o = a.out[i];
+        auto out_desc = [&](int id, int lo, int hi) {
+            S3Out o{};
             o.ptr = buf_ptr(h, id);
             o.stride = h->bufs[id].stride;
             o.width = h->bufs[id].stride;
             o.p16 = h->bufs[id].p16 ? p16_desc(h, id) : P16Desc{nullptr, 0, 0, 0};
-        }
+            o.lo = lo; o.hi = hi < 0 ? o.width : hi;
+            return o;
+        };
+        if (a.nin.on) {
+            // no layer's rows leave the CU; Concat2 = [B2 (conv[L - 1]: channels 0 .. 7) | A1 (the A1 || B1 waves: channels 8 .. 31)]
+            for (int i = 0; i < kS3MaxL; ++i) a.out[i] = S3Out{};
+            a.out[a.L] = out_desc(op.extra_out[0], 0, 8);
+            a.out2 = out_desc(op.extra_out[0], 8, 32);
+        } else
+        for (size_t i = 0; i < op.extra_out.size(); ++i) a.out[i] = out_desc(op.extra_out[i], 0, -1);
         a.redo = redo_flags;
         HIP_TRY(h, stream3_launch(a, grid, stream));
         return DCSCN_OK;

@@ -53,14 +53,17 @@ __device__ __forceinline__ S3RowOut s3_row_out(const S3Out& o, const StreamRow& 
     r.base = r.p16 ? o.p16.base + 128 + pix * (long long)r.rec : reinterpret_cast<char*>(o.ptr) + pix * (long long)r.rec;
     return r;
 }
-// tile n, lane group q: P16 unit 4 n + q of the record (octet 2 n + (q >> 1), part q & 1); float32: channels 16 n + 4 q ..
+// tile n, lane group q: P16 unit 4 n + q of the record (octet 2 n + (q >> 1), part q & 1); float32: channels 16 n + 4 q ..  A destination stores the
+// writer's conv channels [lo, hi) only (B2 writes octet 0 of Concat2, the A1 || B1 waves octets 1 .. 3); none: both pointers null
 __device__ __forceinline__ void s3_store_global(const S3Out& o, const S3RowOut& ro, int col, int n, int q, const u32x4 unit, const f32x4 v) {
     if constexpr ((S3_ABL & 4) != 0) return;
     const unsigned off = (unsigned)col * ro.rec + (unsigned)(n * 64 + q * 16);
     if (ro.p16) {
-        if (2 * n + (q >> 1) < o.p16.octs) *reinterpret_cast<u32x4*>(ro.base + off) = unit;
-    } else if (16 * n + 4 * q < o.width) {
-        *reinterpret_cast<f32x4*>(ro.base + off) = v;
+        const int c8 = 8 * (2 * n + (q >> 1));
+        if (c8 >= o.lo && c8 < o.hi) *reinterpret_cast<u32x4*>(ro.base + off) = unit;
+    } else if (o.ptr != nullptr) {
+        const int c4 = 16 * n + 4 * q;
+        if (c4 >= o.lo && c4 < o.hi) *reinterpret_cast<f32x4*>(ro.base + off) = v;
     }
 }
 
@@ -154,140 +157,158 @@ __device__ __forceinline__ void s3_first_role(const Stream3Args& a, const Stream
 #endif
 }
 
-// ---- CNN2 .. CNNL: a 3x3 conv (NT 16-channel output tiles) from the predecessor's ring ---------------------------------
+// ---- CNN2 .. CNNL (and B2): a 3x3 conv (NT 16-channel output tiles) from the predecessor's ring ---------------------------------
 // OCTS = channel octets of the input ring (compile time: the step count, every LDS offset an immediate or one register per step).
 // One wave per conv: the B operands of a step are read ONCE for all its output tiles -- the kernel is bound by LDS read bandwidth (a
 // ds_read_b128 is 1 KB: ~250 of them per row step and workgroup), not by the MFMAs; the first build (one wave per output tile) read
-// them twice.
+// them twice.  Split in a load part (filter fragments -> registers, for the whole launch) and a step part so that one wave can run
+// several light convs (s3_trio_role).
 template <int OCTS, int NT>
-__device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamArgs& geo, int ci, unsigned lds0, int j0, int rows, int T, int lane) {
+struct S3ConvRegs {
+    static constexpr int STEPS = (9 * OCTS + 3) / 4;
+    h8 fh[STEPS][NT], fl[STEPS][NT];                           // [step][tile][hi | lo][64 lanes][8 halfs] in the blob
+    f32x4 bs[NT], am1[NT];                                     // bias * 2^e, slope - 1
+    unsigned soff[OCTS == 1 ? STEPS : 1];
+    unsigned dyp;
+    StreamCursor cur;
+};
+template <int OCTS, int NT>
+__device__ __forceinline__ void s3_conv_load(const Stream3Args& a, int ci, int lane, S3ConvRegs<OCTS, NT>& r) {
     const S3Conv& c = a.conv[ci];
-    const S3Out& og = a.out[ci + 1];
-    constexpr int STEPS = (9 * OCTS + 3) / 4;
-    constexpr unsigned IN_PX = (unsigned)(2 * OCTS + 1) * 16u, IN_ROW = (unsigned)kStreamRowPx * IN_PX;
-    const int j = lane & 15, q = lane >> 4;
-    // filter fragments of this wave's tile: [step][tile][hi | lo][64 lanes][8 halfs] in the blob
-    h8 fh[STEPS][NT], fl[STEPS][NT];
-    f32x4 bs[NT], am1[NT];
-    {
-        const char* wsrc = reinterpret_cast<const char*>(a.blob + c.w_off);
+    constexpr int STEPS = S3ConvRegs<OCTS, NT>::STEPS;
+    constexpr unsigned IN_PX = (unsigned)(2 * OCTS + 1) * 16u;
+    const int q = lane >> 4;
+    const char* wsrc = reinterpret_cast<const char*>(a.blob + c.w_off);
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                fh[s][n] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((s * NT + n) * 2 + 0) * 64 + lane) * 16);
-                fl[s][n] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((s * NT + n) * 2 + 1) * 64 + lane) * 16);
-            }
+    for (int s = 0; s < STEPS; ++s)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            bs[n] = *reinterpret_cast<const f32x4*>(a.blob + c.ba_off + n * 16 + 4 * q);           // bias * 2^e
-            am1[n] = *reinterpret_cast<const f32x4*>(a.blob + c.ba_off + 32 + n * 16 + 4 * q);     // slope - 1
+            r.fh[s][n] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((s * NT + n) * 2 + 0) * 64 + lane) * 16);
+            r.fl[s][n] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((s * NT + n) * 2 + 1) * 64 + lane) * 16);
         }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        r.bs[n] = *reinterpret_cast<const f32x4*>(a.blob + c.ba_off + n * 16 + 4 * q);           // bias * 2^e
+        r.am1[n] = *reinterpret_cast<const f32x4*>(a.blob + c.ba_off + 32 + n * 16 + 4 * q);     // slope - 1
     }
     // step s, lane group q: pair p = 4 s + q = (tap, octet) with tap = p / OCTS.  For OCTS >= 2 the four lane groups of a step see at most two
     // taps -- tap0 = 4 s / OCTS below the lane-group threshold `thr`, tap0 + 1 from it on -- so row, column and octet offset are compile-time
     // constants selected by one compare; pairs past the last (tap 9) read valid units of tap 8 against zero filters.  OCTS = 1: four taps per
     // step, one offset register per step.
-    unsigned soff[OCTS == 1 ? STEPS : 1];
-    unsigned dyp = 0;
+    r.dyp = 0;
     if constexpr (OCTS == 1) {
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             int tap = 4 * s + q;
             tap = tap > 8 ? 8 : tap;
             const int dy = tap / 3, dx = tap - 3 * dy;
-            soff[s] = (unsigned)dx * IN_PX;
-            dyp |= (unsigned)dy << (2 * s);
+            r.soff[s] = (unsigned)dx * IN_PX;
+            r.dyp |= (unsigned)dy << (2 * s);
         }
-    } else soff[0] = (unsigned)q * 32u;
+    } else r.soff[0] = (unsigned)q * 32u;
+}
+// one step of the conv: stream row g = t - lag from the input ring's rows g - 1 .. g + 1 -> its output ring (four slots: row g goes to its slot
+// while the next layer reads rows g-3 .. g-1 -- ONE barrier per step, issued by the caller) and its global tensor
+// (Issuing the epilogue of row g - 1 between the MFMA groups of row g -- a software pipeline with the layers' lags spaced by three -- was
+// built and measured in r05: 0.83 ms against 0.66, the heaviest wave 7.8 k cycles per step instead of 6.0 k: the ring stores and the B-operand
+// reads share one in-order LGKM counter, and the waits for the one also wait for the other.)
+template <int OCTS, int NT>
+__device__ __forceinline__ void s3_conv_step(const Stream3Args& a, const StreamArgs& geo, int ci, unsigned lds0, int j0, int rows, int t, int lane,
+                                             S3ConvRegs<OCTS, NT>& r, float m1, h2 zero2) {
+    const S3Conv& c = a.conv[ci];
+    const S3Out& og = a.out[ci + 1];
+    constexpr int STEPS = S3ConvRegs<OCTS, NT>::STEPS;
+    constexpr unsigned IN_PX = (unsigned)(2 * OCTS + 1) * 16u, IN_ROW = (unsigned)kStreamRowPx * IN_PX;
+    const int j = lane & 15, q = lane >> 4;
+    const unsigned out_px = (unsigned)c.out.px, out_row = (unsigned)kStreamRowPx * out_px;
+    const int g = t - c.lag;
+    const bool live = g >= 0 && g < rows;
+    u32x4 unit[kStreamMT][NT];
+    bool zero_row = true;
+    if (live) {
+        const StreamRow ri = stream_row(geo, j0, r.cur, g);
+        zero_row = ri.zero;
+        if (!ri.zero) {
+            unsigned rb[3];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) rb[dy] = lds0 + c.in.off + (unsigned)((g + 3 + dy) & 3) * IN_ROW + (unsigned)(3 * j) * IN_PX;   // rows g-1, g, g+1
+            f32x4 acc[kStreamMT][NT];
+            static_for<0, STEPS>([&](auto s_) DCSCN_INL {
+                constexpr int s = decltype(s_)::value;
+                unsigned base;
+                if constexpr (OCTS == 1) {
+                    const unsigned dy = (r.dyp >> (2 * s)) & 3u;
+                    base = (dy == 0 ? rb[0] : dy == 1 ? rb[1] : rb[2]) + r.soff[s];
+                } else {
+                    constexpr int p0 = 4 * s, tap0 = p0 / OCTS, thr = OCTS * (tap0 + 1) - p0;       // lane groups q >= thr are on tap0 + 1
+                    constexpr int ta = tap0 > 8 ? 8 : tap0, tb = tap0 + 1 > 8 ? 8 : tap0 + 1;
+                    constexpr int offa = (ta % 3) * (int)IN_PX + (p0 - OCTS * tap0) * 32, offb = (tb % 3) * (int)IN_PX + (p0 - OCTS * (tap0 + 1)) * 32;
+                    if constexpr (thr > 3) base = rb[ta / 3] + (unsigned)offa + r.soff[0];
+                    else base = (q >= thr ? rb[tb / 3] + (unsigned)offb : rb[ta / 3] + (unsigned)offa) + r.soff[0];
+                }
+                // the three pixel tiles' products interleaved: an accumulator is touched every third MFMA (back to back they wait for each other)
+                h8 xh[kStreamMT], xl[kStreamMT];
+#pragma unroll
+                for (int m = 0; m < kStreamMT; ++m) {
+                    if constexpr ((S3_ABL & 2) != 0) { u32x4 z = {0x3c003c00u, 0x3c003c00u, base, 0x3c003c00u}; asm volatile("" : "+v"(z)); xh[m] = xl[m] = __builtin_bit_cast(h8, z); } else {
+                    xh[m] = __builtin_bit_cast(h8, stream_ld(base + (unsigned)m * IN_PX));
+                    xl[m] = __builtin_bit_cast(h8, stream_ld(base + (unsigned)m * IN_PX + 16u));
+                    }
+                }
+                if constexpr ((S3_ABL & 1) != 0) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int m = 0; m < kStreamMT; ++m) { if (s == 0) acc[m][n] = r.bs[n]; f32x4 tt = acc[m][n]; const h8 fa = r.fh[s][n], fb = r.fl[s][n], xa = xh[m], xb = xl[m]; asm volatile("" : "+v"(tt) : "v"(xa), "v"(xb), "v"(fa), "v"(fb)); acc[m][n] = tt; }
+                } else
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.fl[s][n], xh[m], s == 0 ? r.bs[n] : acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.fh[s][n], xl[m], acc[m][n], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < kStreamMT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(r.fh[s][n], xh[m], acc[m][n], 0, 0, 0);
+                }
+            });
+            float chk = 0.0f;
+            const S3RowOut ro = s3_row_out(og, ri, a.H, a.W);
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m) {
+                const int cx = ri.sx + 3 * j + m;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 v = (S3_ABL & 16) ? acc[m][n] : stream_prelu(acc[m][n] * c.inv, r.am1[n]);
+                    v = cx >= 0 && cx < a.W ? v : kStreamZero;      // SAME padding: columns outside the image are zero in every ring
+                    if constexpr ((S3_ABL & 16) != 0) unit[m][n] = __builtin_bit_cast(u32x4, v); else
+                    unit[m][n] = p16_unit(v, m1, chk, zero2);
+                    if (ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(og, ro, 3 * j + m, n, q, unit[m][n], v);
+                }
+            }
+            if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
+        }
+    }
+    if (live && c.out.px > 0) {
+        const unsigned wb = lds0 + c.out.off + (unsigned)(g & 3) * out_row + (unsigned)(3 * j + 1) * out_px + (unsigned)q * 16u;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+            if (2 * n + (q >> 1) < c.out.octs) {
+#pragma unroll
+                for (int m = 0; m < kStreamMT; ++m) stream_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, zero_row ? kStreamZero : __builtin_bit_cast(f32x4, unit[m][n]));
+            }
+    }
+}
+template <int OCTS, int NT>
+__device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamArgs& geo, int ci, unsigned lds0, int j0, int rows, int T, int lane) {
+    S3ConvRegs<OCTS, NT> r;
+    s3_conv_load<OCTS, NT>(a, ci, lane, r);
     const float m1 = opaque_minus_one();
     const h2 zero2 = p16_opaque_zero2();
-    const unsigned out_px = (unsigned)c.out.px, out_row = (unsigned)kStreamRowPx * out_px;
-    StreamCursor cur;
 #ifdef S3_DBG
     long long dbg_c = 0, dbg_b = 0, dbg_t = __builtin_readcyclecounter();
 #endif
-    // (Issuing the epilogue of row g - 1 between the MFMA groups of row g -- a software pipeline with the layers' lags spaced by three -- was
-    // built and measured in r05: 0.83 ms against 0.66, the heaviest wave 7.8 k cycles per step instead of 6.0 k: the ring stores and the B-operand
-    // reads share one in-order LGKM counter, and the waits for the one also wait for the other.)
     for (int t = 0; t < T; ++t) {
-        const int g = t - c.lag;
-        const bool live = g >= 0 && g < rows;
-        u32x4 unit[kStreamMT][NT];
-        bool zero_row = true;
-        if (live) {
-            const StreamRow ri = stream_row(geo, j0, cur, g);
-            zero_row = ri.zero;
-            if (!ri.zero) {
-                unsigned rb[3];
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) rb[dy] = lds0 + c.in.off + (unsigned)((g + 3 + dy) & 3) * IN_ROW + (unsigned)(3 * j) * IN_PX;   // rows g-1, g, g+1
-                f32x4 acc[kStreamMT][NT];
-                static_for<0, STEPS>([&](auto s_) DCSCN_INL {
-                    constexpr int s = decltype(s_)::value;
-                    unsigned base;
-                    if constexpr (OCTS == 1) {
-                        const unsigned dy = (dyp >> (2 * s)) & 3u;
-                        base = (dy == 0 ? rb[0] : dy == 1 ? rb[1] : rb[2]) + soff[s];
-                    } else {
-                        constexpr int p0 = 4 * s, tap0 = p0 / OCTS, thr = OCTS * (tap0 + 1) - p0;       // lane groups q >= thr are on tap0 + 1
-                        constexpr int ta = tap0 > 8 ? 8 : tap0, tb = tap0 + 1 > 8 ? 8 : tap0 + 1;
-                        constexpr int offa = (ta % 3) * (int)IN_PX + (p0 - OCTS * tap0) * 32, offb = (tb % 3) * (int)IN_PX + (p0 - OCTS * (tap0 + 1)) * 32;
-                        if constexpr (thr > 3) base = rb[ta / 3] + (unsigned)offa + soff[0];
-                        else base = (q >= thr ? rb[tb / 3] + (unsigned)offb : rb[ta / 3] + (unsigned)offa) + soff[0];
-                    }
-                    // the three pixel tiles' products interleaved: an accumulator is touched every third MFMA (back to back they wait for each other)
-                    h8 xh[kStreamMT], xl[kStreamMT];
-#pragma unroll
-                    for (int m = 0; m < kStreamMT; ++m) {
-                        if constexpr ((S3_ABL & 2) != 0) { u32x4 z = {0x3c003c00u, 0x3c003c00u, base, 0x3c003c00u}; asm volatile("" : "+v"(z)); xh[m] = xl[m] = __builtin_bit_cast(h8, z); } else {
-                        xh[m] = __builtin_bit_cast(h8, stream_ld(base + (unsigned)m * IN_PX));
-                        xl[m] = __builtin_bit_cast(h8, stream_ld(base + (unsigned)m * IN_PX + 16u));
-                        }
-                    }
-                    if constexpr ((S3_ABL & 1) != 0) {
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-#pragma unroll
-                            for (int m = 0; m < kStreamMT; ++m) { if (s == 0) acc[m][n] = bs[n]; f32x4 tt = acc[m][n]; const h8 fa = fh[s][n], fb = fl[s][n], xa = xh[m], xb = xl[m]; asm volatile("" : "+v"(tt) : "v"(xa), "v"(xb), "v"(fa), "v"(fb)); acc[m][n] = tt; }
-                    } else
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-#pragma unroll
-                        for (int m = 0; m < kStreamMT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[s][n], xh[m], s == 0 ? bs[n] : acc[m][n], 0, 0, 0);
-#pragma unroll
-                        for (int m = 0; m < kStreamMT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s][n], xl[m], acc[m][n], 0, 0, 0);
-#pragma unroll
-                        for (int m = 0; m < kStreamMT; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[s][n], xh[m], acc[m][n], 0, 0, 0);
-                    }
-                });
-                float chk = 0.0f;
-                const S3RowOut ro = s3_row_out(og, ri, a.H, a.W);
-#pragma unroll
-                for (int m = 0; m < kStreamMT; ++m) {
-                    const int cx = ri.sx + 3 * j + m;
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        f32x4 v = (S3_ABL & 16) ? acc[m][n] : stream_prelu(acc[m][n] * c.inv, am1[n]);
-                        v = cx >= 0 && cx < a.W ? v : kStreamZero;      // SAME padding: columns outside the image are zero in every ring
-                        if constexpr ((S3_ABL & 16) != 0) unit[m][n] = __builtin_bit_cast(u32x4, v); else
-                        unit[m][n] = p16_unit(v, m1, chk, zero2);
-                        if (ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(og, ro, 3 * j + m, n, q, unit[m][n], v);
-                    }
-                }
-                if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
-            }
-        }
-        // four ring slots: row g goes to its slot while the next layer reads rows g-3 .. g-1 -- ONE barrier per step
-        if (live && c.out.px > 0) {
-            const unsigned wb = lds0 + c.out.off + (unsigned)(g & 3) * out_row + (unsigned)(3 * j + 1) * out_px + (unsigned)q * 16u;
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-                if (2 * n + (q >> 1) < c.out.octs) {
-#pragma unroll
-                    for (int m = 0; m < kStreamMT; ++m) stream_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, zero_row ? kStreamZero : __builtin_bit_cast(f32x4, unit[m][n]));
-                }
-        }
+        s3_conv_step<OCTS, NT>(a, geo, ci, lds0, j0, rows, t, lane, r, m1, zero2);
 #ifdef S3_DBG
         const long long tb = __builtin_readcyclecounter();
         dbg_c += tb - dbg_t;
@@ -301,6 +322,111 @@ __device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamA
 #ifdef S3_DBG
     if (a.dbg && blockIdx.x == 0 && lane == 0) { long long* d = a.dbg + (threadIdx.x >> 6) * 4; d[0] = dbg_c; d[1] = dbg_b; d[2] = T; }
 #endif
+}
+
+// ---- the light trio (nin.on): conv[L - 3], conv[L - 2] (one output tile each) and B2 = conv[L - 1] in ONE wave -- they are different stream rows
+// of the same step, run one after the other; together fewer MFMAs than CNN2's wave (c-DCSCN: 45 + 45 + 27 against 162) ------------------------
+template <int O1, int O2>
+__device__ __forceinline__ void s3_trio_role(const Stream3Args& a, const StreamArgs& geo, unsigned lds0, int j0, int rows, int T, int lane) {
+    S3ConvRegs<O1, 1> r1;
+    S3ConvRegs<O2, 1> r2;
+    S3ConvRegs<1, 1> r3;
+    const int c1 = a.L - 3, c2 = a.L - 2, c3 = a.L - 1;
+    s3_conv_load<O1, 1>(a, c1, lane, r1);
+    s3_conv_load<O2, 1>(a, c2, lane, r2);
+    s3_conv_load<1, 1>(a, c3, lane, r3);
+    const float m1 = opaque_minus_one();
+    const h2 zero2 = p16_opaque_zero2();
+    for (int t = 0; t < T; ++t) {
+        s3_conv_step<O1, 1>(a, geo, c1, lds0, j0, rows, t, lane, r1, m1, zero2);
+        s3_conv_step<O2, 1>(a, geo, c2, lds0, j0, rows, t, lane, r2, m1, zero2);
+        s3_conv_step<1, 1>(a, geo, c3, lds0, j0, rows, t, lane, r3, m1, zero2);
+        stream_barrier();
+    }
+}
+
+// ---- A1 || B1 (nin.on): the 1x1 GEMM over the concat of all L layers, accumulated as the layers' rows appear -- H_concat never exists, no
+// feature map goes to HBM.  Output channels [B1 (8) | A1 (24)] = two 16-channel tiles, ONE wave per tile: layer i's row g is
+// in its ring from step g + 2 i + 1 on, so the accumulators of a row are live for R = 2 L - 1 steps -- R rows x 3 pixel tiles x 4 registers (156 for
+// L = 7) -- with the slot of a row a compile-time constant of (step mod R, layer): the step loop is unrolled R times.  A layer is one K = 32 step (its
+// <= 4 octets; lane groups past the last octet re-read the last one against zero filters).  The row layer L - 1 completes is finished: scale,
+// PReLU, split; channels 0 .. 7 (B1) go to the B1 ring for B2 (s3_trio_role), channels 8 .. 31 (A1) to Concat2 behind B2's octet.
+template <int L>
+__device__ __forceinline__ void s3_nin_role(const Stream3Args& a, const StreamArgs& geo, int n, unsigned lds0, int j0, int rows, int T, int lane) {
+    constexpr int R = 2 * L - 1;
+    const int j = lane & 15, q = lane >> 4;
+    h8 fh[L], fl[L];
+    {
+        const char* wsrc = reinterpret_cast<const char*>(a.blob + a.nin.w_off);
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            fh[i] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((i * 2 + n) * 2 + 0) * 64 + lane) * 16);
+            fl[i] = *reinterpret_cast<const h8*>(wsrc + ((size_t)((i * 2 + n) * 2 + 1) * 64 + lane) * 16);
+        }
+    }
+    // (156 accumulator + 56 fragment registers: everything else is re-derived per step -- ring addresses from the lane, bias / slope from the blob)
+    const float* ba = a.blob + a.nin.ba_off + n * 16 + 4 * q;        // bias * 2^e; slope - 1 at + 32
+    const float m1 = opaque_minus_one();
+    const h2 zero2 = p16_opaque_zero2();
+    const unsigned b1_px = (unsigned)a.nin.b1.px, b1_row = (unsigned)kStreamRowPx * b1_px;
+    f32x4 acc[R][kStreamMT];
+    StreamCursor cur;
+    auto step = [&](auto p_, int t) DCSCN_INL {
+        constexpr int p = decltype(p_)::value;                     // t mod R
+        static_for<0, L>([&](auto i_) DCSCN_INL {
+            constexpr int i = decltype(i_)::value;
+            constexpr int s = ((p - 2 * i - 1) % R + R) % R;       // accumulator slot of the row layer i contributes to at this step
+            const int g = t - 2 * i - 1;
+            if (g >= 0 && g < rows) {                               // (wave uniform)
+                const S3Ring& rg = i == 0 ? a.first_out : a.conv[i > 0 ? i - 1 : 0].out;
+                int le = lane;
+                asm volatile("" : "+v"(le));                         // (keeps the per-layer addresses out of the registers between steps)
+                const int je = le & 15, qe = le >> 4;
+                const int qq = qe < rg.octs ? qe : rg.octs - 1;      // (octets past the layer's last: any valid unit of the pixel, the filter rows are zero)
+                const unsigned px = (unsigned)rg.px;
+                const unsigned b = lds0 + (unsigned)rg.off + ((unsigned)(g & 3) * (unsigned)kStreamRowPx + (unsigned)(3 * je + 1)) * px + (unsigned)qq * 32u;
+                h8 xh[kStreamMT], xl[kStreamMT];
+#pragma unroll
+                for (int m = 0; m < kStreamMT; ++m) {
+                    xh[m] = __builtin_bit_cast(h8, stream_ld(b + (unsigned)m * px));
+                    xl[m] = __builtin_bit_cast(h8, stream_ld(b + (unsigned)m * px + 16u));
+                }
+                f32x4 bs = kStreamZero;
+                if constexpr (i == 0) bs = *reinterpret_cast<const f32x4*>(ba);
+#pragma unroll
+                for (int m = 0; m < kStreamMT; ++m) acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], xh[m], i == 0 ? bs : acc[s][m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < kStreamMT; ++m) acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], xl[m], acc[s][m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < kStreamMT; ++m) acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], xh[m], acc[s][m], 0, 0, 0);
+            }
+        });
+        constexpr int sl = ((p - 2 * (L - 1) - 1) % R + R) % R;
+        const int g = t - 2 * (L - 1) - 1;                          // the row the last layer just completed
+        if (g >= 0 && g < rows) {
+            const StreamRow ri = stream_row(geo, j0, cur, g);
+            const S3RowOut ro = s3_row_out(a.out2, ri, a.H, a.W);
+            float chk = 0.0f;
+            const f32x4 am1 = *reinterpret_cast<const f32x4*>(ba + 32);
+            const unsigned wb = lds0 + (unsigned)a.nin.b1.off + (unsigned)(g & 3) * b1_row + (unsigned)(3 * j + 1) * b1_px + (unsigned)q * 16u;
+#pragma unroll
+            for (int m = 0; m < kStreamMT; ++m) {
+                const int cx = ri.sx + 3 * j + m;
+                f32x4 v = stream_prelu(acc[sl][m] * a.nin.inv, am1);
+                v = !ri.zero && cx >= 0 && cx < a.W ? v : kStreamZero;      // SAME padding for B2: zero rows and columns outside the image are zeros in the ring
+                const u32x4 unit = p16_unit(v, m1, chk, zero2);
+                if (!ri.zero && ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(a.out2, ro, 3 * j + m, n, q, unit, v);
+                if (n == 0 && q < 2) stream_st(wb + (unsigned)m * b1_px, __builtin_bit_cast(f32x4, unit));      // B1 = channels 0 .. 7: the octet's hi and lo units
+            }
+            if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
+        }
+        stream_barrier();
+    };
+    for (int t = 0; t < T; t += R)
+        static_for<0, R>([&](auto p_) DCSCN_INL {
+            constexpr int p = decltype(p_)::value;
+            if (t + p < T) step(p_, t + p);
+        });
 }
 
 // one workgroup = n_waves <= 8 waves (CNN1 + one per conv; pack.hip: the role table), one per CU (the rings take most of the LDS)
@@ -321,6 +447,14 @@ __global__ __launch_bounds__(512) void feat3_stream(const Stream3Args a) {
     const int T = rows + a.total_lag;
     const int ci = a.role_conv[wave];
     if (ci < 0) s3_first_role(a, geo, lds0, j0, rows, T, lane);
+    else if (ci >= kS3RoleTrio) {
+        // (instantiated for the c-DCSCN shape: the last two feature layers read two octets each; graph.hip: fuse_feat3_stream checks)
+        s3_trio_role<2, 2>(a, geo, lds0, j0, rows, T, lane);
+#ifndef S3_NO_NIN
+    } else if (ci >= kS3RoleNin) s3_nin_role<7>(a, geo, ci - kS3RoleNin, lds0, j0, rows, T, lane);
+#else
+    } else if (ci >= kS3RoleNin) { }
+#endif
     else {
         const bool two = a.conv[ci].tiles == 2;
         switch (a.conv[ci].in.octs) {

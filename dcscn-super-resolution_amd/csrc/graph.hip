@@ -746,26 +746,53 @@ void fuse_feat3_stream(dcscn_ctx* h) {
         for (int k = 0; k < i; ++k)
             if (h->ops[k].out_buf[0] == o.out_buf[0]) return;
     }
+    // r06: A1 || B1 and B2 inside the launch (feat3_stream.hpp: s3_nin_role / s3_trio_role; option "stream_nin") -- no feature map goes to HBM, Concat2
+    // [B2 | A1] is the launch's only output.  Instantiated for the c-DCSCN shape: L = 7, B1 = one octet, A1 || B1 = 32 channels, the last two
+    // feature layers read two octets and write one tile; anything else keeps the r05 plan (the layers' rows to global memory, conv_nin_h behind).
+    bool nin_on = false;
+    if (h->stream_nin && c.use_nin && L == 7 && c.nin_filters2 == 8 && c.nin_filters == 24 && (int)h->ops.size() >= L + 2) {
+        const Op& nin = h->ops[L];
+        const Op& b2 = h->ops[L + 1];
+        auto octs = [&](int i) { return (h->sched[i] + 7) / 8; };
+        bool ok = nin.kind == OP_CONV && nin.ks == 1 && nin.dwk == 0 && nin.segs.size() == 2 && nin.act == ACT_ALPHA && nin.ps == 1 && !nin.residual &&
+                  nin.segs[0].dw1 < 0 && nin.segs[1].dw1 < 0 && (int)nin.multi.size() == L && nin.out_buf[0] >= 0 && nin.out_buf[1] >= 0 &&
+                  nin.out_off[0] == 0 && nin.out_off[1] == 8 && nin.cin == [&] { int k = 0; for (int i = 0; i < L; ++i) k += h->sched[i]; return k; }();
+        for (int i = 0; ok && i < L; ++i) ok = nin.multi[i].first == h->ops[i].out_buf[0];
+        ok = ok && b2.kind == OP_CONV && b2.ks == 3 && b2.dwk == 0 && b2.cin == 8 && b2.cout == 8 && b2.act == ACT_ALPHA && b2.ps == 1 && !b2.residual &&
+             b2.segs.size() == 1 && b2.in_buf == nin.out_buf[0] && b2.in_off == 0 && b2.out_buf[0] == nin.out_buf[1] && b2.out_off[0] == 0 &&
+             b2.split >= (1 << 29) && b2.tconv_s == 0 && b2.fold_s == 0 && b2.res == 1 && h->bufs[nin.out_buf[1]].stride == 32;
+        ok = ok && octs(L - 3) == 2 && octs(L - 2) == 2 && h->sched[L - 2] <= 16 && h->sched[L - 1] <= 16;
+        const size_t lds2 = lds + (size_t)4 * kStreamRowPx * (2 * octs(L - 1) + 1) * 16 + (size_t)4 * kStreamRowPx * 3 * 16;
+        nin_on = ok && lds2 <= 158 * 1024;
+    }
     Op f;
     f.kind = OP_STREAM3;
-    f.name = "CNN1.." + h->ops[L - 1].name + " (streamed)";
+    f.name = "CNN1.." + h->ops[nin_on ? L + 1 : L - 1].name + " (streamed)";
     f.ks = 3;
     f.cin = 1;
-    f.cout = h->sched[L - 1];
+    f.cout = nin_on ? c.nin_filters + c.nin_filters2 : h->sched[L - 1];
     f.res = 1;
     f.act = ACT_ALPHA;
     f.in_buf = EXT_X;
-    f.out_buf[0] = f.out_buf[1] = h->ops[L - 1].out_buf[0];
-    f.out_width[0] = pad4(h->sched[L - 1]);
-    f.halo = L;
+    f.out_buf[0] = f.out_buf[1] = nin_on ? h->ops[L].out_buf[1] : h->ops[L - 1].out_buf[0];
+    f.out_width[0] = nin_on ? 32 : pad4(h->sched[L - 1]);
+    f.halo = nin_on ? L + 1 : L;
     f.bytes = 4;
-    for (int i = 0; i < L; ++i) {
+    const int n_rep = nin_on ? L + 2 : L;
+    for (int i = 0; i < n_rep; ++i) {
         f.macs += h->ops[i].macs;
-        f.bytes += 4 * (int64_t)pad4(h->sched[i]);
+        if (!nin_on) {
+            f.bytes += 4 * (int64_t)pad4(h->sched[i]);
+            f.extra_out.push_back(h->ops[i].out_buf[0]);
+        }
         f.fused.push_back(h->ops[i]);
-        f.extra_out.push_back(h->ops[i].out_buf[0]);
     }
-    h->ops.erase(h->ops.begin(), h->ops.begin() + L);
+    if (nin_on) {
+        f.bytes += 4 * 32;
+        f.extra_out.push_back(f.out_buf[0]);
+        f.stream3.nin.on = 1;                                    // (pack_feat3_stream fills the rest)
+    }
+    h->ops.erase(h->ops.begin(), h->ops.begin() + n_rep);
     h->ops.insert(h->ops.begin(), f);
 }
 

@@ -236,11 +236,20 @@ hipError_t stream_launch(const StreamArgs& a, int grid, bool f16, hipStream_t st
 // ---- row-streamed feature extractor of the NON-separable narrow nets (feat3_stream.hpp) ----
 constexpr int kS3MaxL = 8;         // feature layers
 constexpr int kS3MaxWaves = 8;     // CNN1 + one per conv
+constexpr int kS3RoleTrio = 32, kS3RoleNin = 16;
 struct S3Ring { int32_t off, px, octs; };              // LDS byte offset of [4 slots][kStreamRowPx][px bytes] P16 units; px = (2 octs + 1) * 16 (0: no ring)
-struct S3Out {                     // a layer's global tensor: P16 (p16.base != nullptr) or float32 NHWC
+struct S3Out {                     // a global tensor of the launch: P16 (p16.base != nullptr), float32 NHWC (ptr != nullptr) or none (both null: not stored)
     P16Desc p16;
     float* ptr;
     int32_t stride, width;         // floats per pixel, stored channels (multiple of 4)
+    int32_t lo, hi;                // conv channels [lo, hi) of the writer are stored, at the same channel index of the tensor (multiples of 8; hi <= width)
+};
+struct S3Nin {                     // A1 || B1 accumulated inside the launch (feat3_stream.hpp: s3_nin_role), B2 behind it
+    int32_t on;                    // 0: the layers' rows go to global memory and conv_nin_h reads them (r05)
+    int32_t w_off;                 // blob offset (floats) of the fragments [layer][tile][hi | lo][64 lanes][8 halfs]: K = the layer's <= 4 octets, zero beyond; x 2^e
+    int32_t ba_off;                // blob offset of bias * 2^e [32], slope - 1 [32], channel order [B1 (8) | A1 (24)]
+    float inv;                     // 2^-e
+    S3Ring b1;                     // ring of B1 rows (one octet)
 };
 struct S3Conv {
     S3Ring in, out;
@@ -256,12 +265,15 @@ struct Stream3Args {
     int32_t N, H, W;
     int32_t n_strips, useful_w, halo, n_blocks, useful_h, rows_c, n_jobs, jobs_per_wg;      // as StreamArgs
     int32_t L, total_lag, n_waves;
-    int8_t role_conv[kS3MaxWaves]; // wave -> -1: CNN1, else conv index (0 = CNN2)
-    int8_t role_tile[kS3MaxWaves]; // ... and its output tile
+    int8_t role_conv[kS3MaxWaves]; // wave -> -1: CNN1, 0 .. L - 2: that conv (0 = CNN2); with nin.on also kS3RoleTrio (conv[L - 3], conv[L - 2] and B2 = conv[L - 1]
+                                   // in one wave) and kS3RoleNin + n (A1 || B1, output tile n)
+    int8_t role_tile[kS3MaxWaves]; // (unused)
     int32_t first_w;               // blob offset of CNN1: filter [9][32], bias [32], slope - 1 [32]
     S3Ring first_out;
     S3Conv conv[kS3MaxL];
-    S3Out out[kS3MaxL];            // out[0] = CNN1's tensor, out[i + 1] = conv i's
+    S3Out out[kS3MaxL];            // out[0] = CNN1's tensor, out[i + 1] = conv i's (nin.on: none for the layers, out[L] = Concat2 channels [0, 8) for B2)
+    S3Nin nin;
+    S3Out out2;                    // nin.on: Concat2 [B2 | A1], channels [8, 32) written by the A1 || B1 waves
     int32_t ring_bytes;
     int32_t* redo;                 // [0] pass flag, [1 + image] (split16.hpp)
     long long* dbg;                // S3_DBG builds (tools/s3_abl.sh probe): per wave of workgroup 0: [0] cycles in compute, [1] cycles waiting at the barrier, [2] steps

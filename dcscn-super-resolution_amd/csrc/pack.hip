@@ -748,7 +748,8 @@ int pack_feat_stream(dcscn_ctx* h, Op& op) {
 
 // ---- feat3_stream (feat3_stream.hpp): rings, role table and filter fragments of the fused CNN1 .. CNNL launch ---------------------
 int pack_feat3_stream(dcscn_ctx* h, Op& op) {
-    const int L = (int)op.fused.size();
+    const bool nin_on = op.stream3.nin.on != 0;                 // fuse_feat3_stream: B1+A1 and B2 are part of the launch (op.fused[L], op.fused[L + 1])
+    const int L = (int)op.fused.size() - (nin_on ? 2 : 0);
     for (Op& sub : op.fused) {                      // the layers' own launches: the float32 plan of a flagged image, and split16 = 0
         const int rc = finalize_op(h, sub);
         if (rc) return rc;
@@ -756,14 +757,20 @@ int pack_feat3_stream(dcscn_ctx* h, Op& op) {
     Stream3Args& a = op.stream3;
     a = Stream3Args{};
     a.L = L;
-    a.total_lag = 2 * (L - 1);
+    a.nin.on = nin_on ? 1 : 0;
+    a.total_lag = nin_on ? 2 * L + 1 : 2 * (L - 1);             // (B2 computes stream row t - (2 L + 1): two behind the row A1 || B1 finishes at step g + 2 L - 1)
     auto tens = [&](int id) -> const std::vector<float>& { return h->tensors[id].data; };
     int lds = 0;
     std::vector<S3Ring> ring(L);
     for (int i = 0; i < L; ++i) {
         const int octs = (h->sched[i] + 7) / 8;
-        ring[i] = S3Ring{lds, i + 1 < L ? (2 * octs + 1) * 16 : 0, octs};
-        if (i + 1 < L) lds += 4 * kStreamRowPx * ring[i].px;         // four slots (feat3_stream.hpp)
+        const bool has = i + 1 < L || nin_on;                    // the last layer's rows are read by the A1 || B1 waves only
+        ring[i] = S3Ring{lds, has ? (2 * octs + 1) * 16 : 0, octs};
+        if (has) lds += 4 * kStreamRowPx * ring[i].px;           // four slots (feat3_stream.hpp)
+    }
+    if (nin_on) {
+        a.nin.b1 = S3Ring{lds, 3 * 16, 1};
+        lds += 4 * kStreamRowPx * a.nin.b1.px;
     }
     a.ring_bytes = lds;
     if (lds > 160 * 1024) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream needs %d bytes of LDS", lds);
@@ -783,25 +790,21 @@ int pack_feat3_stream(dcscn_ctx* h, Op& op) {
             blob[320 + co] = (sg.alpha >= 0 ? tens(sg.alpha)[sg.col0 + co] : c1.const_alpha) - 1.0f;
         }
     }
-    int waves = 0;
-    std::vector<int> cost;                          // MFMAs per row of each wave
-    a.role_conv[waves] = -1; a.role_tile[waves] = 0; cost.push_back(0); ++waves;
-    for (int i = 1; i < L; ++i) {
-        const Op& o = op.fused[i];
+    // a 3x3 conv of the stream: conv[ci] computes `cout` channels from the `cin` channels of ring `in`; fragments [step][tile][hi | lo][64 lanes][8 halfs]
+    auto pack_conv = [&](int ci, const Op& o, int cin, int cout, const S3Ring& in, const S3Ring& out, int lag) {
         const ColSeg& sg = o.segs[0];
-        const int cin = h->sched[i - 1], cout = h->sched[i];
-        const int octs = ring[i - 1].octs, steps = (9 * octs + 3) / 4, tiles = (cout + 15) / 16;
-        S3Conv& cv = a.conv[i - 1];
-        cv.in = ring[i - 1];
-        cv.out = ring[i];
-        cv.lag = 2 * i;
+        const int octs = in.octs, steps = (9 * octs + 3) / 4, tiles = (cout + 15) / 16;
+        S3Conv& cv = a.conv[ci];
+        cv.in = in;
+        cv.out = out;
+        cv.lag = lag;
         cv.tiles = tiles;
         const std::vector<float>& w = tens(sg.w);              // [3, 3, cin, cout_total]
         const int wcols = (int)h->tensors[sg.w].shape.back();
         std::vector<float> all((size_t)9 * cin * cout);
         for (int t = 0; t < 9; ++t)
-            for (int ci = 0; ci < cin; ++ci)
-                for (int co = 0; co < cout; ++co) all[((size_t)t * cin + ci) * cout + co] = w[((size_t)t * cin + ci) * wcols + sg.col0 + co];
+            for (int c0 = 0; c0 < cin; ++c0)
+                for (int co = 0; co < cout; ++co) all[((size_t)t * cin + c0) * cout + co] = w[((size_t)t * cin + c0) * wcols + sg.col0 + co];
         const int e = split16_scale_exp(all.data(), all.size());
         cv.inv = std::ldexp(1.0f, -e);
         cv.w_off = (int)blob.size();
@@ -815,8 +818,8 @@ int pack_feat3_stream(dcscn_ctx* h, Op& op) {
                     uint16_t* hi = d16 + ((size_t)((s * tiles + n) * 2 + 0) * 64 + lane) * 8;
                     uint16_t* lo = d16 + ((size_t)((s * tiles + n) * 2 + 1) * 64 + lane) * 8;
                     for (int t8 = 0; t8 < 8; ++t8) {
-                        const int ci = 8 * oct + t8;
-                        const float wv = tap < 9 && ci < cin && co < cout ? all[((size_t)tap * cin + ci) * cout + co] : 0.0f;
+                        const int c0 = 8 * oct + t8;
+                        const float wv = tap < 9 && c0 < cin && co < cout ? all[((size_t)tap * cin + c0) * cout + co] : 0.0f;
                         split16_host(std::ldexp(wv, e), &hi[t8], &lo[t8]);
                     }
                 }
@@ -826,8 +829,70 @@ int pack_feat3_stream(dcscn_ctx* h, Op& op) {
             blob[cv.ba_off + co] = std::ldexp(sg.b >= 0 ? tens(sg.b)[sg.col0 + co] : 0.0f, e);
             blob[cv.ba_off + 32 + co] = (sg.alpha >= 0 ? tens(sg.alpha)[sg.col0 + co] : o.const_alpha) - 1.0f;
         }
+        return 9 * steps * tiles;                               // MFMAs per row
+    };
+    int waves = 0;
+    std::vector<int> cost;                          // MFMAs per row of each wave
+    a.role_conv[waves] = -1; a.role_tile[waves] = 0; cost.push_back(0); ++waves;
+    int trio_cost = 0;
+    for (int i = 1; i < L; ++i) {
+        const int mf = pack_conv(i - 1, op.fused[i], h->sched[i - 1], h->sched[i], ring[i - 1], ring[i], 2 * i);
+        if (nin_on && i >= L - 2) { trio_cost += mf; continue; }               // conv[L - 3], conv[L - 2]: in the trio's wave
         if (waves >= kS3MaxWaves) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream needs more than %d waves", kS3MaxWaves);
-        a.role_conv[waves] = (int8_t)(i - 1); a.role_tile[waves] = 0; cost.push_back(9 * steps * tiles); ++waves;
+        a.role_conv[waves] = (int8_t)(i - 1); a.role_tile[waves] = 0; cost.push_back(mf); ++waves;
+    }
+    if (nin_on) {
+        const dcscn_config& c = h->cfg;
+        const int nb = c.nin_filters2, na = c.nin_filters;      // 8, 24 (fuse_feat3_stream)
+        const Op& nin = op.fused[L];
+        const Op& b2 = op.fused[L + 1];
+        trio_cost += pack_conv(L - 1, b2, nb, nb, a.nin.b1, S3Ring{0, 0, 1}, 2 * L + 1);
+        if (waves + 3 > kS3MaxWaves) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream with A1 || B1 needs more than %d waves", kS3MaxWaves);
+        a.role_conv[waves] = (int8_t)kS3RoleTrio; cost.push_back(trio_cost); ++waves;
+        // A1 || B1: conv channel c < nb = B1 channel c, else A1 channel c - nb; the K axis layer by layer, one K = 32 fragment per (layer, tile)
+        const ColSeg& sb = nin.segs[0];
+        const ColSeg& sa = nin.segs[1];
+        const std::vector<float>& wb = tens(sb.w);             // [1, 1, K, nb_total]
+        const std::vector<float>& wa = tens(sa.w);
+        const int bcols = (int)h->tensors[sb.w].shape.back(), acols = (int)h->tensors[sa.w].shape.back();
+        int ktot = 0;
+        for (int i = 0; i < L; ++i) ktot += h->sched[i];
+        std::vector<float> all((size_t)ktot * 32, 0.0f);
+        for (int k = 0; k < ktot; ++k) {
+            for (int co = 0; co < nb; ++co) all[(size_t)k * 32 + co] = wb[(size_t)k * bcols + sb.col0 + co];
+            for (int co = 0; co < na; ++co) all[(size_t)k * 32 + nb + co] = wa[(size_t)k * acols + sa.col0 + co];
+        }
+        const int e = split16_scale_exp(all.data(), all.size());
+        a.nin.inv = std::ldexp(1.0f, -e);
+        a.nin.w_off = (int)blob.size();
+        blob.resize(blob.size() + (size_t)L * 2 * 2 * 64 * 4, 0.0f);
+        uint16_t* d16 = reinterpret_cast<uint16_t*>(&blob[a.nin.w_off]);
+        int k0 = 0;
+        for (int i = 0; i < L; ++i) {
+            for (int n = 0; n < 2; ++n)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int q = lane >> 4, co = 16 * n + (lane & 15);
+                    uint16_t* hi = d16 + ((size_t)((i * 2 + n) * 2 + 0) * 64 + lane) * 8;
+                    uint16_t* lo = d16 + ((size_t)((i * 2 + n) * 2 + 1) * 64 + lane) * 8;
+                    for (int t8 = 0; t8 < 8; ++t8) {
+                        const int c0 = 8 * q + t8;                 // (a lane group past the layer's last octet re-reads that octet: zero rows here)
+                        const float wv = c0 < h->sched[i] && 8 * q < 8 * ring[i].octs ? all[(size_t)(k0 + c0) * 32 + co] : 0.0f;
+                        split16_host(std::ldexp(wv, e), &hi[t8], &lo[t8]);
+                    }
+                }
+            k0 += h->sched[i];
+        }
+        a.nin.ba_off = (int)blob.size();
+        blob.resize(blob.size() + 64, 0.0f);
+        for (int co = 0; co < nb; ++co) {
+            blob[a.nin.ba_off + co] = std::ldexp(sb.b >= 0 ? tens(sb.b)[sb.col0 + co] : 0.0f, e);
+            blob[a.nin.ba_off + 32 + co] = (sb.alpha >= 0 ? tens(sb.alpha)[sb.col0 + co] : nin.const_alpha) - 1.0f;
+        }
+        for (int co = 0; co < na; ++co) {
+            blob[a.nin.ba_off + nb + co] = std::ldexp(sa.b >= 0 ? tens(sa.b)[sa.col0 + co] : 0.0f, e);
+            blob[a.nin.ba_off + 32 + nb + co] = (sa.alpha >= 0 ? tens(sa.alpha)[sa.col0 + co] : nin.const_alpha) - 1.0f;
+        }
+        for (int n = 0; n < 2; ++n) { a.role_conv[waves] = (int8_t)(kS3RoleNin + n); cost.push_back(9 * L); ++waves; }
     }
     a.n_waves = waves;
     {   // wave w runs on SIMD w & 3: deal the roles, heaviest first, onto the least loaded SIMD that has a wave slot left

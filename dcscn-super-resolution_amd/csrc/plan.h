@@ -199,6 +199,7 @@ struct dcscn_ctx {
     hipGraphExec_t graph_exec = nullptr;
     bool winograd = true;                    // 3x3 convs as Winograd F(2x2,3x3) where it pays
     bool stream_tail = true;                 // the x4 tail of the same nets as one launch (fuse_tail_stream)
+    bool stream_nin = true;                  // ... with A1 || B1 and B2 inside that launch where the shape allows (option "stream_nin"; 0: the r05 plan)
     bool stream_dense = true;                // non-separable narrow nets: CNN1 .. CNNL as one row-streamed launch (fuse_feat3_stream; option "stream_dense")
     bool stream_features = true;             // separable narrow nets: CNN1 .. B2 as one row-streamed launch (fuse_feat_stream)
     int split16_mask = 3;                    // debugging aid (option "split16" 2 / 3): bit 0 = conv3_h, bit 1 = conv_nin_h

@@ -177,6 +177,10 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * the c-DCSCN checkpoints) run CNN1 .. CNNL as one row-streamed launch on the f16 matrix pipe (csrc/feat3_stream.hpp: three-row rings of
  * pre-split units in LDS, filter fragments in registers, every layer's rows written once for A1 || B1); with split16 = 0, and for a
  * flagged image, the layers run one by one.  0 = always layer by layer.
+ * "stream_nin" (default 1; before dcscn_finalize only): in that launch also A1 || B1 -- accumulated in registers as the layers' rows appear in
+ * their LDS rings -- and B2, where the net has the c-DCSCN shape (7 feature layers, nin_filters 24, nin_filters2 8): no feature map is
+ * written to device memory, Concat2 [B2 | A1] is the launch's only output (DCSCN.py:258-291).  0 = every layer's rows go to device memory
+ * and the 1x1 GEMM reads them back (the r05 plan; same function, f32 results differ by accumulation order only).
  * "split16" (default 1; any time): the 3x3 convs the Winograd kernel would take and the wide 1x1 convs run their contraction
  * on the f16 matrix pipe at f32 accuracy -- every f32 operand as an f16 (hi, lo) pair, three products per MAC, f32
  * accumulation; measured error at the f32 kernels' level (profiles/r03_f16x3_numerics.txt).  Weights are scaled

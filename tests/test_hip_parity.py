@@ -934,3 +934,47 @@ def test_streamed_dense_feature_extractor(oracle, scale):
         err, err0 = float(np.max(np.abs(y - ref))), float(np.max(np.abs(y0 - ref)))
         print("x%d %dx%dx%d: streamed max-abs %.3g, layer by layer %.3g" % (scale, n, h, w, err, err0))
         assert np.isfinite(y).all() and err <= MAX_ABS_TOL and err0 <= MAX_ABS_TOL
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4])
+def test_streamed_nin_keeps_the_feature_maps_out_of_hbm(oracle, scale):
+    """r06: with the c-DCSCN shape the streamed launch also accumulates A1 || B1 as the layers' rows appear and runs B2
+    behind it -- the launch list loses B1+A1 and B2, Concat2 is the launch's only output -- within the same bars of the float64 oracle on
+    patches, column strips, row blocks, a ragged batch and a 1-pixel image; stream_nin = 0 is the r05 plan (same bars)."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS["L7_F32to8_x%d" % scale])
+    weights = oracle.synthetic_weights(cfg, seed=31)
+    for n, h, w in ((3, 48, 48), (1, 37, 131), (1, 300, 20), (5, 17, 33), (2, 1, 1), (1, 64, 50)):
+        x, x2 = synthetic_batch(n, h, w, scale, seed=32)
+        ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+        with engine.Engine(cfg, device=0) as eng:
+            eng.load_weights(weights)
+            ops = eng.ops()
+            assert ops[0]["kernel"] == "feat3_stream" and ops[0]["name"].startswith("CNN1..B2"), ops
+            assert not [o for o in ops if o["name"] in ("B1+A1", "B2")], ops
+            y = eng.forward(x, x2)
+            assert np.array_equal(y, eng.forward(x, x2))                      # deterministic
+        with engine.Engine(cfg, device=0) as eng:
+            eng.set_option("stream_nin", 0)
+            eng.load_weights(weights)
+            names = [o["name"] for o in eng.ops()]
+            assert "B1+A1" in names and "B2" in names and eng.ops()[0]["kernel"] == "feat3_stream"
+            y0 = eng.forward(x, x2)
+        err, err0 = float(np.max(np.abs(y - ref))), float(np.max(np.abs(y0 - ref)))
+        print("x%d %dx%dx%d: A1 || B1 in the launch max-abs %.3g, conv_nin_h behind it %.3g" % (scale, n, h, w, err, err0))
+        assert np.isfinite(y).all() and err <= MAX_ABS_TOL and err0 <= MAX_ABS_TOL
+    # the bare residual branch (last conv unattenuated, x2 = 0) at the relative bar of test_residual_branch_relative_error, both plans
+    weights = oracle.synthetic_weights(cfg, seed=33)
+    last = "R-CNN%d" % cfg["reconstruct_layers"]
+    weights[last + "/conv_W"] = weights[last + "/conv_W"] * 100.0
+    x, _ = synthetic_batch(2, 48, 48, scale, seed=34)
+    x2 = np.zeros((2, 48 * scale, 48 * scale, 1), np.float32)
+    ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+    for nin in (1, 0):
+        with engine.Engine(cfg, device=0) as eng:
+            eng.set_option("stream_nin", nin)
+            eng.load_weights(weights)
+            y = eng.forward(x, x2)
+        rel = float(np.max(np.abs(y - ref)) / np.max(np.abs(ref)))
+        print("x%d bare branch, stream_nin %d: relative %.3g" % (scale, nin, rel))
+        assert rel <= 5e-6
