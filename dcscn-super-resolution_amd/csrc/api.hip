@@ -180,10 +180,16 @@ int dcscn_finalize(dcscn_handle h) {
             rc = upload(h, op.h16.h_tab16.data(), op.h16.h_tab16.size() * sizeof(NinSrcQuad), (void**)&op.h16.d_tab16);
             if (rc) return rc;
         }
-        if (!op.multi.empty()) {
+        auto alloc_srctab = [&](Op& o) {
+            if (o.multi.empty()) return (int)DCSCN_OK;
             // 4 quads per 16-channel chunk of conv_nin; conv_nin_h walks the same table 8 quads per 32-channel chunk
-            op.h_srctab.assign(std::max<size_t>((size_t)4 * op.n_chunks, (size_t)8 * ((op.cin_phys + kNinHKC - 1) / kNinHKC)), NinSrcQuad{0, 0, 0});
-            rc = upload(h, op.h_srctab.data(), op.h_srctab.size() * sizeof(NinSrcQuad), (void**)&op.d_srctab);
+            o.h_srctab.assign(std::max<size_t>((size_t)4 * o.n_chunks, (size_t)8 * ((o.cin_phys + kNinHKC - 1) / kNinHKC)), NinSrcQuad{0, 0, 0});
+            return upload(h, o.h_srctab.data(), o.h_srctab.size() * sizeof(NinSrcQuad), (void**)&o.d_srctab);
+        };
+        rc = alloc_srctab(op);
+        if (rc) return rc;
+        for (Op& sub : op.fused) {                      // (the 1x1 GEMM inside a streamed launch: its own float32 launch reads the layers' tensors)
+            rc = alloc_srctab(sub);
             if (rc) return rc;
         }
     }

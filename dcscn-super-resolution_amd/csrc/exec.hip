@@ -468,8 +468,14 @@ int run_forward(dcscn_ctx* h, const float* x, const float* x2, float* y, int n, 
     if (rc) return rc;
     if (h->tables_gen != h->carve_gen) {
         // the multi-source tables hold arena addresses: refill them behind the re-carve, on the launch stream
+        std::vector<Op*> with_tables;                   // the launches of the plan and the ones inside a streamed launch (its float32 plan)
         for (Op& op : h->ops) {
-            if (op.multi.empty()) continue;
+            with_tables.push_back(&op);
+            for (Op& sub : op.fused) with_tables.push_back(&sub);
+        }
+        for (Op* opp : with_tables) {
+            Op& op = *opp;
+            if (op.multi.empty() || !op.d_srctab) continue;
             // float32 form: one entry per channel quad of the pad-8 virtual K axis (densify_features); padding quads point at readable
             // memory with stride 0 (conv_nin_h fetches every quad; their filter rows are zero)
             const unsigned long long pad_ptr = (unsigned long long)(uintptr_t)buf_ptr(h, op.multi[0].first);

@@ -12,7 +12,7 @@ hipError_t stream3_launch(const Stream3Args& a, int grid, hipStream_t stream) {
     Stream3Args b = a;
     if (!d_dbg) (void)hipMalloc((void**)&d_dbg, 8 * 4 * sizeof(long long));
     b.dbg = d_dbg;
-    hipLaunchKernelGGL(feat3_stream, dim3(grid), dim3(a.n_waves * 64), (size_t)a.ring_bytes, stream, b);
+    hipLaunchKernelGGL(feat3_stream, dim3(grid), dim3(a.n_waves * 64), (size_t)a.ring_bytes + 256, stream, b);
     if (getenv("DCSCN_S3_DBG")) {
         long long host[32];
         (void)hipStreamSynchronize(stream);
@@ -23,7 +23,7 @@ hipError_t stream3_launch(const Stream3Args& a, int grid, hipStream_t stream) {
     }
     return hipGetLastError();
 #endif
-    hipLaunchKernelGGL(feat3_stream, dim3(grid), dim3(a.n_waves * 64), (size_t)a.ring_bytes, stream, a);
+    hipLaunchKernelGGL(feat3_stream, dim3(grid), dim3(a.n_waves * 64), (size_t)a.ring_bytes + 256, stream, a);
     return hipGetLastError();
 }
 

@@ -111,7 +111,9 @@ __device__ __forceinline__ void s3_first_role(const Stream3Args& a, const Stream
         const bool live = g < rows;
         if (live) {
             const StreamRow ri = stream_row(geo, j0, cc, g);
-            const S3RowOut ro = s3_row_out(a.out[0], ri, a.H, a.W);
+            const bool to_global = a.out[0].ptr != nullptr || a.out[0].p16.base != nullptr;    // (wave uniform)
+            S3RowOut ro{};
+            if (to_global) ro = s3_row_out(a.out[0], ri, a.H, a.W);
             float chk = 0.0f;
             const unsigned wb = lds0 + a.first_out.off + (unsigned)(g & 3) * out_row + (unsigned)(3 * j + 1) * out_px + (unsigned)q * 16u;
 #pragma unroll
@@ -128,7 +130,7 @@ __device__ __forceinline__ void s3_first_role(const Stream3Args& a, const Stream
                     f32x4 v = stream_prelu(bs[n] + s, al[n]);
                     v = ok ? v : kStreamZero;
                     const u32x4 unit = p16_unit(v, m1, chk, zero2);
-                    if (ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(a.out[0], ro, 3 * j + m, n, q, unit, v);
+                    if (to_global && ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(a.out[0], ro, 3 * j + m, n, q, unit, v);
                     // (four ring slots: row g goes to its slot while CNN2 reads rows g-3 .. g-1; ONE barrier per step)
                     if (2 * n + (q >> 1) < a.first_out.octs) stream_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, __builtin_bit_cast(f32x4, unit));
                 }
@@ -272,7 +274,9 @@ __device__ __forceinline__ void s3_conv_step(const Stream3Args& a, const StreamA
                 }
             });
             float chk = 0.0f;
-            const S3RowOut ro = s3_row_out(og, ri, a.H, a.W);
+            const bool to_global = og.ptr != nullptr || og.p16.base != nullptr;      // (wave uniform; nin.on: only B2 has a global tensor)
+            S3RowOut ro{};
+            if (to_global) ro = s3_row_out(og, ri, a.H, a.W);
 #pragma unroll
             for (int m = 0; m < kStreamMT; ++m) {
                 const int cx = ri.sx + 3 * j + m;
@@ -282,7 +286,7 @@ __device__ __forceinline__ void s3_conv_step(const Stream3Args& a, const StreamA
                     v = cx >= 0 && cx < a.W ? v : kStreamZero;      // SAME padding: columns outside the image are zero in every ring
                     if constexpr ((S3_ABL & 16) != 0) unit[m][n] = __builtin_bit_cast(u32x4, v); else
                     unit[m][n] = p16_unit(v, m1, chk, zero2);
-                    if (ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(og, ro, 3 * j + m, n, q, unit[m][n], v);
+                    if (to_global && ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(og, ro, 3 * j + m, n, q, unit[m][n], v);
                 }
             }
             if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
@@ -324,25 +328,35 @@ __device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamA
 #endif
 }
 
-// ---- the light trio (nin.on): conv[L - 3], conv[L - 2] (one output tile each) and B2 = conv[L - 1] in ONE wave -- they are different stream rows
-// of the same step, run one after the other; together fewer MFMAs than CNN2's wave (c-DCSCN: 45 + 45 + 27 against 162) ------------------------
+// ---- two light convs in ONE wave (nin.on: A1 || B1 takes two waves of the eight): they compute different stream rows of the same step, one
+// after the other.  c-DCSCN: (CNN6, CNN7) = 45 + 45 MFMAs and (CNN5, B2) = 63 + 27 against CNN2's 162 ------------------------------------
 template <int O1, int O2>
-__device__ __forceinline__ void s3_trio_role(const Stream3Args& a, const StreamArgs& geo, unsigned lds0, int j0, int rows, int T, int lane) {
+__device__ __forceinline__ void s3_pair_role(const Stream3Args& a, const StreamArgs& geo, int c1, int c2, unsigned lds0, int j0, int rows, int T, int lane) {
     S3ConvRegs<O1, 1> r1;
     S3ConvRegs<O2, 1> r2;
-    S3ConvRegs<1, 1> r3;
-    const int c1 = a.L - 3, c2 = a.L - 2, c3 = a.L - 1;
     s3_conv_load<O1, 1>(a, c1, lane, r1);
     s3_conv_load<O2, 1>(a, c2, lane, r2);
-    s3_conv_load<1, 1>(a, c3, lane, r3);
     const float m1 = opaque_minus_one();
     const h2 zero2 = p16_opaque_zero2();
+#ifdef S3_DBG
+    long long dbg_c = 0, dbg_b = 0, dbg_t = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t < T; ++t) {
         s3_conv_step<O1, 1>(a, geo, c1, lds0, j0, rows, t, lane, r1, m1, zero2);
         s3_conv_step<O2, 1>(a, geo, c2, lds0, j0, rows, t, lane, r2, m1, zero2);
-        s3_conv_step<1, 1>(a, geo, c3, lds0, j0, rows, t, lane, r3, m1, zero2);
+#ifdef S3_DBG
+        const long long tb = __builtin_readcyclecounter();
+        dbg_c += tb - dbg_t;
+#endif
         stream_barrier();
+#ifdef S3_DBG
+        dbg_t = __builtin_readcyclecounter();
+        dbg_b += dbg_t - tb;
+#endif
     }
+#ifdef S3_DBG
+    if (a.dbg && blockIdx.x == 0 && lane == 0) { long long* d = a.dbg + (threadIdx.x >> 6) * 4; d[0] = dbg_c; d[1] = dbg_b; d[2] = T; }
+#endif
 }
 
 // ---- A1 || B1 (nin.on): the 1x1 GEMM over the concat of all L layers, accumulated as the layers' rows appear -- H_concat never exists, no
@@ -355,6 +369,12 @@ template <int L>
 __device__ __forceinline__ void s3_nin_role(const Stream3Args& a, const StreamArgs& geo, int n, unsigned lds0, int j0, int rows, int T, int lane) {
     constexpr int R = 2 * L - 1;
     const int j = lane & 15, q = lane >> 4;
+#ifndef S3_NIN_PRIO
+#define S3_NIN_PRIO 1
+#endif
+    // this wave's step is seven short dependent blocks (ring reads -> nine MFMAs): behind its SIMD partner's bursts of 27 - 54 MFMAs each of them
+    // would wait; with priority its few MFMAs go first and the partner loses nothing it can measure
+    if (S3_NIN_PRIO) asm volatile("s_setprio 1");
     h8 fh[L], fl[L];
     {
         const char* wsrc = reinterpret_cast<const char*>(a.blob + a.nin.w_off);
@@ -365,12 +385,15 @@ __device__ __forceinline__ void s3_nin_role(const Stream3Args& a, const StreamAr
         }
     }
     // (156 accumulator + 56 fragment registers: everything else is re-derived per step -- ring addresses from the lane, bias / slope from the blob)
-    const float* ba = a.blob + a.nin.ba_off + n * 16 + 4 * q;        // bias * 2^e; slope - 1 at + 32
+    const unsigned ba = lds0 + (unsigned)a.ring_bytes + (unsigned)(n * 16 + 4 * q) * 4u;    // bias * 2^e, slope - 1 at + 128 bytes: copied behind the rings at kernel start
     const float m1 = opaque_minus_one();
     const h2 zero2 = p16_opaque_zero2();
     const unsigned b1_px = (unsigned)a.nin.b1.px, b1_row = (unsigned)kStreamRowPx * b1_px;
     f32x4 acc[R][kStreamMT];
     StreamCursor cur;
+#ifdef S3_DBG
+    long long dbg_c = 0, dbg_b = 0, dbg_t = __builtin_readcyclecounter();
+#endif
     auto step = [&](auto p_, int t) DCSCN_INL {
         constexpr int p = decltype(p_)::value;                     // t mod R
         static_for<0, L>([&](auto i_) DCSCN_INL {
@@ -392,7 +415,7 @@ __device__ __forceinline__ void s3_nin_role(const Stream3Args& a, const StreamAr
                     xl[m] = __builtin_bit_cast(h8, stream_ld(b + (unsigned)m * px + 16u));
                 }
                 f32x4 bs = kStreamZero;
-                if constexpr (i == 0) bs = *reinterpret_cast<const f32x4*>(ba);
+                if constexpr (i == 0) bs = stream_ld(ba);
 #pragma unroll
                 for (int m = 0; m < kStreamMT; ++m) acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], xh[m], i == 0 ? bs : acc[s][m], 0, 0, 0);
 #pragma unroll
@@ -407,7 +430,7 @@ __device__ __forceinline__ void s3_nin_role(const Stream3Args& a, const StreamAr
             const StreamRow ri = stream_row(geo, j0, cur, g);
             const S3RowOut ro = s3_row_out(a.out2, ri, a.H, a.W);
             float chk = 0.0f;
-            const f32x4 am1 = *reinterpret_cast<const f32x4*>(ba + 32);
+            const f32x4 am1 = stream_ld(ba + 128u);
             const unsigned wb = lds0 + (unsigned)a.nin.b1.off + (unsigned)(g & 3) * b1_row + (unsigned)(3 * j + 1) * b1_px + (unsigned)q * 16u;
 #pragma unroll
             for (int m = 0; m < kStreamMT; ++m) {
@@ -420,13 +443,24 @@ __device__ __forceinline__ void s3_nin_role(const Stream3Args& a, const StreamAr
             }
             if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
         }
+#ifdef S3_DBG
+        const long long tb = __builtin_readcyclecounter();
+        dbg_c += tb - dbg_t;
+#endif
         stream_barrier();
+#ifdef S3_DBG
+        dbg_t = __builtin_readcyclecounter();
+        dbg_b += dbg_t - tb;
+#endif
     };
     for (int t = 0; t < T; t += R)
         static_for<0, R>([&](auto p_) DCSCN_INL {
             constexpr int p = decltype(p_)::value;
             if (t + p < T) step(p_, t + p);
         });
+#ifdef S3_DBG
+    if (a.dbg && blockIdx.x == 0 && lane == 0) { long long* d = a.dbg + (threadIdx.x >> 6) * 4; d[0] = dbg_c; d[1] = dbg_b; d[2] = T; }
+#endif
 }
 
 // one workgroup = n_waves <= 8 waves (CNN1 + one per conv; pack.hip: the role table), one per CU (the rings take most of the LDS)
@@ -438,6 +472,7 @@ __global__ __launch_bounds__(512) void feat3_stream(const Stream3Args a) {
     {
         f32x4* s4 = reinterpret_cast<f32x4*>(smem);
         for (int i = tid; i < a.ring_bytes / 16; i += blockDim.x) s4[i] = kStreamZero;
+        if (a.nin.on && tid < 16) s4[a.ring_bytes / 16 + tid] = reinterpret_cast<const f32x4*>(a.blob + a.nin.ba_off)[tid];     // A1 || B1: bias * 2^e [32], slope - 1 [32]
         __syncthreads();
     }
     const StreamArgs geo = s3_geometry(a);
@@ -447,9 +482,11 @@ __global__ __launch_bounds__(512) void feat3_stream(const Stream3Args a) {
     const int T = rows + a.total_lag;
     const int ci = a.role_conv[wave];
     if (ci < 0) s3_first_role(a, geo, lds0, j0, rows, T, lane);
-    else if (ci >= kS3RoleTrio) {
-        // (instantiated for the c-DCSCN shape: the last two feature layers read two octets each; graph.hip: fuse_feat3_stream checks)
-        s3_trio_role<2, 2>(a, geo, lds0, j0, rows, T, lane);
+    else if (ci >= kS3RolePair) {
+        // (instantiated for the c-DCSCN shape; graph.hip: fuse_feat3_stream checks: pair 0 = conv[L - 3], conv[L - 2] reading two octets each,
+        //  pair 1 = conv[L - 4] reading three octets and B2 = conv[L - 1] reading B1's one)
+        if (ci == kS3RolePair) s3_pair_role<2, 2>(a, geo, a.L - 3, a.L - 2, lds0, j0, rows, T, lane);
+        else s3_pair_role<3, 1>(a, geo, a.L - 4, a.L - 1, lds0, j0, rows, T, lane);
 #ifndef S3_NO_NIN
     } else if (ci >= kS3RoleNin) s3_nin_role<7>(a, geo, ci - kS3RoleNin, lds0, j0, rows, T, lane);
 #else

@@ -761,7 +761,8 @@ void fuse_feat3_stream(dcscn_ctx* h) {
         ok = ok && b2.kind == OP_CONV && b2.ks == 3 && b2.dwk == 0 && b2.cin == 8 && b2.cout == 8 && b2.act == ACT_ALPHA && b2.ps == 1 && !b2.residual &&
              b2.segs.size() == 1 && b2.in_buf == nin.out_buf[0] && b2.in_off == 0 && b2.out_buf[0] == nin.out_buf[1] && b2.out_off[0] == 0 &&
              b2.split >= (1 << 29) && b2.tconv_s == 0 && b2.fold_s == 0 && b2.res == 1 && h->bufs[nin.out_buf[1]].stride == 32;
-        ok = ok && octs(L - 3) == 2 && octs(L - 2) == 2 && h->sched[L - 2] <= 16 && h->sched[L - 1] <= 16;
+        // the pair roles are instantiated for: conv[L - 4] reads three octets, conv[L - 3] and conv[L - 2] two; one output tile each
+        ok = ok && octs(L - 4) == 3 && octs(L - 3) == 2 && octs(L - 2) == 2 && h->sched[L - 3] <= 16 && h->sched[L - 2] <= 16 && h->sched[L - 1] <= 16;
         const size_t lds2 = lds + (size_t)4 * kStreamRowPx * (2 * octs(L - 1) + 1) * 16 + (size_t)4 * kStreamRowPx * 3 * 16;
         nin_on = ok && lds2 <= 158 * 1024;
     }

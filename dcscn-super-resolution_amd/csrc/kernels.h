@@ -236,7 +236,7 @@ hipError_t stream_launch(const StreamArgs& a, int grid, bool f16, hipStream_t st
 // ---- row-streamed feature extractor of the NON-separable narrow nets (feat3_stream.hpp) ----
 constexpr int kS3MaxL = 8;         // feature layers
 constexpr int kS3MaxWaves = 8;     // CNN1 + one per conv
-constexpr int kS3RoleTrio = 32, kS3RoleNin = 16;
+constexpr int kS3RolePair = 32, kS3RoleNin = 16;      // role codes beyond the conv indices (feat3_stream.hpp)
 struct S3Ring { int32_t off, px, octs; };              // LDS byte offset of [4 slots][kStreamRowPx][px bytes] P16 units; px = (2 octs + 1) * 16 (0: no ring)
 struct S3Out {                     // a global tensor of the launch: P16 (p16.base != nullptr), float32 NHWC (ptr != nullptr) or none (both null: not stored)
     P16Desc p16;
@@ -265,8 +265,8 @@ struct Stream3Args {
     int32_t N, H, W;
     int32_t n_strips, useful_w, halo, n_blocks, useful_h, rows_c, n_jobs, jobs_per_wg;      // as StreamArgs
     int32_t L, total_lag, n_waves;
-    int8_t role_conv[kS3MaxWaves]; // wave -> -1: CNN1, 0 .. L - 2: that conv (0 = CNN2); with nin.on also kS3RoleTrio (conv[L - 3], conv[L - 2] and B2 = conv[L - 1]
-                                   // in one wave) and kS3RoleNin + n (A1 || B1, output tile n)
+    int8_t role_conv[kS3MaxWaves]; // wave -> -1: CNN1, 0 .. L - 2: that conv (0 = CNN2); with nin.on also kS3RolePair + 0 (conv[L - 3] and conv[L - 2] in one wave),
+                                   // kS3RolePair + 1 (conv[L - 4] and B2 = conv[L - 1]) and kS3RoleNin + n (A1 || B1, output tile n)
     int8_t role_tile[kS3MaxWaves]; // (unused)
     int32_t first_w;               // blob offset of CNN1: filter [9][32], bias [32], slope - 1 [32]
     S3Ring first_out;

@@ -834,10 +834,11 @@ int pack_feat3_stream(dcscn_ctx* h, Op& op) {
     int waves = 0;
     std::vector<int> cost;                          // MFMAs per row of each wave
     a.role_conv[waves] = -1; a.role_tile[waves] = 0; cost.push_back(0); ++waves;
-    int trio_cost = 0;
+    int pair_cost[2] = {0, 0};
     for (int i = 1; i < L; ++i) {
         const int mf = pack_conv(i - 1, op.fused[i], h->sched[i - 1], h->sched[i], ring[i - 1], ring[i], 2 * i);
-        if (nin_on && i >= L - 2) { trio_cost += mf; continue; }               // conv[L - 3], conv[L - 2]: in the trio's wave
+        if (nin_on && i >= L - 2) { pair_cost[0] += mf; continue; }             // conv[L - 3], conv[L - 2] share a wave
+        if (nin_on && i == L - 3) { pair_cost[1] += mf; continue; }             // conv[L - 4] shares one with B2
         if (waves >= kS3MaxWaves) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream needs more than %d waves", kS3MaxWaves);
         a.role_conv[waves] = (int8_t)(i - 1); a.role_tile[waves] = 0; cost.push_back(mf); ++waves;
     }
@@ -846,9 +847,9 @@ int pack_feat3_stream(dcscn_ctx* h, Op& op) {
         const int nb = c.nin_filters2, na = c.nin_filters;      // 8, 24 (fuse_feat3_stream)
         const Op& nin = op.fused[L];
         const Op& b2 = op.fused[L + 1];
-        trio_cost += pack_conv(L - 1, b2, nb, nb, a.nin.b1, S3Ring{0, 0, 1}, 2 * L + 1);
-        if (waves + 3 > kS3MaxWaves) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream with A1 || B1 needs more than %d waves", kS3MaxWaves);
-        a.role_conv[waves] = (int8_t)kS3RoleTrio; cost.push_back(trio_cost); ++waves;
+        pair_cost[1] += pack_conv(L - 1, b2, nb, nb, a.nin.b1, S3Ring{0, 0, 1}, 2 * L + 1);
+        if (waves + 4 > kS3MaxWaves) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: feat3_stream with A1 || B1 needs more than %d waves", kS3MaxWaves);
+        for (int k = 0; k < 2; ++k) { a.role_conv[waves] = (int8_t)(kS3RolePair + k); cost.push_back(pair_cost[k] + 60); ++waves; }   // (+ a second conv's fixed work)
         // A1 || B1: conv channel c < nb = B1 channel c, else A1 channel c - nb; the K axis layer by layer, one K = 32 fragment per (layer, tile)
         const ColSeg& sb = nin.segs[0];
         const ColSeg& sa = nin.segs[1];
