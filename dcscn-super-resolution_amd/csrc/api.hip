@@ -167,6 +167,7 @@ int dcscn_finalize(dcscn_handle h) {
     fuse_feat_stream(h);
     densify_features(h);
     fuse_feat3_stream(h);
+    fold_whole_tail(h);                         // x3 / x4: whatever tail the rewrites above left becomes the float32 plan of ONE folded launch
     for (Op& op : h->ops) {
         int rc = finalize_op(h, op);
         if (rc) return rc;
@@ -217,7 +218,7 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     snprintf(out->name, sizeof out->name, "%s", op.name.c_str());
     const bool s16 = op_on_split16(h, op);
     const bool h8 = op_takes_h8(h, op);                          // (the predicate launch_op itself uses)
-    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (s16 ? (op.shape.nin ? "conv_nin_h" : op.fold_s > 0 ? "conv5_h" : h8 ? "conv3_h8" : "conv3_h") : op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : op.kind == OP_STREAM3 ? (s16 ? "feat3_stream" : "layer by layer") : "depthwise");
+    snprintf(out->kernel, sizeof out->kernel, "%s", op.kind == OP_CONV ? (s16 ? (op.shape.nin ? "conv_nin_h" : op.fold_s > 0 ? "conv5_h" : h8 ? "conv3_h8" : "conv3_h") : op.shape.wino ? "conv_wino2" : op.shape.nin ? "conv_nin" : "conv_igemm") : op.kind == OP_CIN1 ? "conv_cin1" : op.kind == OP_COUT1 ? "conv_cout1" : op.kind == OP_STREAM ? "feat_stream" : op.kind == OP_TAIL ? "tail_stream" : op.kind == OP_STREAM3 ? (s16 ? "feat3_stream" : "layer by layer") : op.kind == OP_FOLDX ? (s16 ? "conv5_h" : "layer by layer") : "depthwise");
     out->kernel_size = op.ks;
     out->in_channels = op.cin;
     out->out_channels = op.cout;
@@ -228,6 +229,10 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out) {
     out->macs_per_lr_pixel = op.macs;
     out->bytes_per_lr_pixel = op.bytes;
     out->executed_macs_per_lr_pixel = op.macs;
+    if (op.kind == OP_FOLDX && h->finalized && s16) {
+        out->nt = 1; out->kc = 32; out->n_tiles = 1;
+        out->executed_macs_per_lr_pixel = 3 * 25 * (int64_t)op.h16.n_chunks * 32 * 16;      // (the border ring's launch repeats 8 % of it on a 48 x 48 patch)
+    }
     if (op.kind == OP_CONV && h->finalized) {
         const int64_t r2 = (int64_t)op.res * op.res;
         const int64_t k_exec = (int64_t)op.n_chunks * op.shape.kc;             // padded input channels
@@ -268,6 +273,11 @@ int dcscn_set_option(dcscn_handle h, const char* key, int64_t value) {
     }
     if (!strcmp(key, "spatial_tiling")) {
         h->spatial_tiling = value != 0;
+        return DCSCN_OK;
+    }
+    if (!strcmp(key, "fold_whole_tail")) {
+        if (h->finalized) return fail(h, DCSCN_ERR_STATE, "the fold_whole_tail option must be set before dcscn_finalize");
+        h->fold_whole = value != 0;
         return DCSCN_OK;
     }
     if (!strcmp(key, "fold_linear_tail")) {

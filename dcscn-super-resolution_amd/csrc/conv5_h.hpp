@@ -236,6 +236,43 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
     const float zero = opaque_zero();
     float chk = 0.0f;
     float* yout = a.out0.ptr;
+    if constexpr (NT == 1) {
+        if (a.fold == 2) {
+            // whole-tail fold (graph.hip: fold_whole_tail): conv channel 4 lk + r = sub-pixel phase (pa, pb) = (p / ps, p % ps) of the ps x ps block of LR
+            // pixel (gy, gx), interior kernel; the pixels of the image's border ring are computed by fold_border (their kernels differ)
+            const bool col_in = gx > 0 && gx < W - 1;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + G::BA_BASE + lk * 16);
+            static_for<0, 4>([&](auto m_) DCSCN_INL {
+                constexpr int m = decltype(m_)::value;
+                const int gy = y0 + 4 * wave + m;
+                if (col_in && gy > 0 && gy < H - 1) {
+                    chk = nonfinite_acc(chk, acc[m][0], zero);
+                    const f32x4 v = acc[m][0] * inv + bv;
+                    if (ps == 4) {                             // phases 4 lk .. 4 lk + 3 = HR row 4 gy + lk, columns 4 gx .. 4 gx + 3: one 16-byte store
+                        const size_t idx = ((size_t)(img * H + gy) * 4 + lk) * orow + (size_t)gx * 4;
+                        f32x4 o = v;
+                        if (a.res) o = o + *reinterpret_cast<const f32x4*>(a.res + idx);
+                        *reinterpret_cast<f32x4*>(yout + idx) = o;
+                    } else {
+                        const float vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int p = 4 * lk + r;
+                            if (p < ps * ps) {
+                                const int pa = p / ps, pb = p - pa * ps;
+                                const size_t idx = ((size_t)(img * H + gy) * ps + pa) * orow + (size_t)(gx * ps + pb);
+                                float out = vr[r];
+                                if (a.res) out += a.res[idx];
+                                yout[idx] = out;
+                            }
+                        }
+                    }
+                }
+            });
+            if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + img] = 1; }
+            return;
+        }
+    }
     static_for<0, NT>([&](auto n_) DCSCN_INL {
         constexpr int n = decltype(n_)::value;
         const int phase = n * 4 + lk;
@@ -260,6 +297,197 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
         }
     });
     if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + img] = 1; }     // the image goes to the float32 plan (exec.hip)
+}
+
+// fold_border: the border ring of a whole-tail fold (ConvArgs::fold == 2).  On the first / last row and column of an image the composite kernel
+// differs from the interior one -- the zero padding of the intermediate maps (the shuffled maps at 2x / 4x resolution, the HR map the last conv
+// reads) drops taps there, and with them the bias terms they carry -- so every (vy, vx) in {interior, first, last, both}^2 has its own 5x5 kernel
+// and bias (pack.hip: pack_foldx).  One wave = one JOB = 16 pixels that share a variant, the 16 columns of the MFMA's B operand:
+//   * 16 consecutive pixels of the first / last row (columns 1 .. W - 2) or of the first / last column (rows 1 .. H - 2) of one image: the
+//     5 x 20-pixel window the 25 taps read is staged ONCE in the wave's own 12.5 KB of LDS (conv3_h's unit swizzle: conflict-free reads for
+//     all five shifts), a tap's B operand is two ds_read_b128 -- the first build fetched every tap's pixels from the tensor: 5 x the bytes
+//     through L2, 46 of its 98 us per 1024 patches (tools/fb_abl.sh);
+//   * the same corner of 16 consecutive images (no window to share: every lane fetches its taps straight from the tensor).
+// A fragments come from the variant's pack_conv16 image (L2 resident), a tap row at a time; 25 taps x chunks x 3 MFMAs per job; no
+// workgroup barrier (a wave's LDS traffic is in order).  8 % of the pixels of a 48 x 48 patch, 1.5 % of a 256 x 256 image.
+#ifndef FB_ABL
+#define FB_ABL 0      // timing-only builds (tools/fb_abl.sh; results wrong by design): 1 no pixel fetches, 2 no filter fetches, 4 no stores / residual reads, 8 no MFMAs
+#endif
+constexpr int kFbWinBytes = 5 * 20 * 128;      // a job's window: 5 lines across x 20 pixels along x one 128-byte record
+struct FoldBorderJobs {             // job list of a launch (host and device)
+    int segs_w, segs_h, rows_n, cols_n, j_img, cb;
+    long long img_jobs, total;
+};
+__host__ __device__ inline FoldBorderJobs fold_border_jobs(int N, int H, int W) {
+    FoldBorderJobs j;
+    j.segs_w = W > 2 ? (W - 2 + 15) / 16 : 0; j.segs_h = H > 2 ? (H - 2 + 15) / 16 : 0;
+    j.rows_n = H > 1 ? 2 : 1; j.cols_n = W > 1 ? 2 : 1;
+    j.j_img = j.rows_n * j.segs_w + j.cols_n * j.segs_h;
+    j.cb = (N + 15) / 16;
+    j.img_jobs = (long long)N * j.j_img;
+    j.total = j.img_jobs + (long long)j.rows_n * j.cols_n * j.cb;
+    return j;
+}
+
+template <bool IN16>
+__global__ __launch_bounds__(256, 2) void fold_border(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_fb[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lj = lane & 15, lk = lane >> 4;
+    const int H = a.H, W = a.W, N = a.N, ps = a.ps;
+    const FoldBorderJobs jb = fold_border_jobs(N, H, W);
+    const long long job = (long long)blockIdx.x * 4 + wave;
+    if (job >= jb.total) return;
+    // the lane's pixel (img, y, x); row / column jobs: (by, bx) = the pixel of lane column 0, along_x = the 16 pixels run along x
+    int img, y, x, vy, vx, by = 0, bx = 0;
+    bool valid, along_x = true;
+    const bool corner = job >= jb.img_jobs;                   // (wave uniform)
+    if (!corner) {
+        img = (int)(job / jb.j_img);
+        int r = (int)(job - (long long)img * jb.j_img);
+        if (r < jb.rows_n * jb.segs_w) {
+            const int which = r / jb.segs_w, seg = r - which * jb.segs_w;
+            by = which ? H - 1 : 0; bx = 1 + 16 * seg;
+            y = by; x = bx + lj; valid = x <= W - 2;
+            vy = H == 1 ? 3 : which ? 2 : 1; vx = 0;
+        } else {
+            r -= jb.rows_n * jb.segs_w;
+            const int which = r / jb.segs_h, seg = r - which * jb.segs_h;
+            bx = which ? W - 1 : 0; by = 1 + 16 * seg;
+            x = bx; y = by + lj; valid = y <= H - 2;
+            vx = W == 1 ? 3 : which ? 2 : 1; vy = 0;
+            along_x = false;
+        }
+    } else {
+        const int r = (int)(job - jb.img_jobs);
+        const int c = r / jb.cb, batch = r - c * jb.cb;
+        const int cy = c / jb.cols_n, cx = c - cy * jb.cols_n;
+        y = cy ? H - 1 : 0; x = cx ? W - 1 : 0;
+        img = 16 * batch + lj; valid = img < N;
+        vy = H == 1 ? 3 : cy ? 2 : 1; vx = W == 1 ? 3 : cx ? 2 : 1;
+    }
+    const int v = __builtin_amdgcn_readfirstlane(vy * 4 + vx);
+    const int n_chunks = a.n_chunks;
+    const char* fv = reinterpret_cast<const char*>(a.wpack16) + (size_t)v * n_chunks * (25 * 2048) + lane * 16;
+    const float m1 = opaque_minus_one();
+    char* win = smem_fb + wave * kFbWinBytes;
+    int rd[5];                                                 // window reads: the lane's unit of position lj + shift of line 0
+#pragma unroll
+    for (int sh = 0; sh < 5; ++sh) rd[sh] = (lj + sh) * 128 + c3h_unit(lj + sh, lk, 0) * 16;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        const char* fc = fv + (size_t)chunk * (25 * 2048);
+        int rem = 4;
+        unsigned rec = 0;
+        const char* base16 = nullptr;
+        if constexpr (IN16) {
+            rem = a.in16.octs - 4 * chunk;
+            rec = rem >= 4 ? 128u : 32u * (unsigned)rem;
+            base16 = a.in16.base + (long long)chunk * a.in16.plane;
+        }
+        // the (hi | lo) units of octet kq of pixel (gi, yy, xx); ok = false: zeros
+        auto fetch16 = [&](int gi, int yy, int xx, int kq, bool ok, h8& hi, h8& lo) DCSCN_INL {
+            if constexpr ((FB_ABL & 1) != 0) { u32x4 z = {0x3c003c00u, (unsigned)(ok ? xx : yy), 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(z)); hi = lo = __builtin_bit_cast(h8, z); return; }
+            if constexpr (IN16) {
+                // (pixels outside the image and octets past the tensor's last read the plane's zero record)
+                const unsigned off = ok && kq < rem ? 128u + (unsigned)((gi * H + yy) * W + xx) * rec + (unsigned)kq * 32u : (unsigned)kq * 32u;
+                hi = *reinterpret_cast<const h8*>(base16 + (size_t)off);
+                lo = *reinterpret_cast<const h8*>(base16 + (size_t)off + 16);
+            } else {
+                const int c0 = chunk * 32 + 8 * kq;
+                const float* p = a.in + ((size_t)((ok ? gi : 0) * H + (ok ? yy : 0)) * W + (ok ? xx : 0)) * a.in_stride + a.in_off + c0;
+                f32x4 q0 = {0.0f, 0.0f, 0.0f, 0.0f}, q1 = q0;
+                if (ok && c0 < a.cin_phys) q0 = *reinterpret_cast<const f32x4*>(p);
+                if (ok && c0 + 4 < a.cin_phys) q1 = *reinterpret_cast<const f32x4*>(p + 4);
+                split8(q0, q1, m1, hi, lo);
+            }
+        };
+        if (!corner) {
+            // ---- window -> LDS: item t = (window pixel t >> 2 = (line across, position along), octet t & 3); 400 items, 7 per lane ----
+            if (chunk > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the previous chunk's reads are done before its window is overwritten)
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int t = i * 64 + lane;
+                const int wp = t >> 2, kq = t & 3;
+                const int ac = wp / 20, al = wp - ac * 20;
+                const int yy = along_x ? by + ac - 2 : by + al - 2, xx = along_x ? bx + al - 2 : bx + ac - 2;
+                const bool ok = t < 400 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                h8 hi, lo;
+                fetch16(img, yy, xx, kq, ok, hi, lo);
+                if (t < 400) {
+                    const int u = c3h_unit(al, kq, 0);
+                    *reinterpret_cast<h8*>(win + wp * 128 + u * 16) = hi;
+                    *reinterpret_cast<h8*>(win + wp * 128 + (u ^ 1) * 16) = lo;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              // a wave's LDS accesses execute in order: no barrier
+        }
+        // a LINE of the window at a time (line a across, shift s along: tap (a, s) for row jobs, (s, a) for column jobs): its 5 filter fragments
+        // (and, corner jobs, 5 pixel fetches) are issued together, then the 15 MFMAs
+#pragma unroll
+        for (int la = 0; la < 5; ++la) {
+            h8 wh[5], wl[5], xh[5], xl[5];
+#pragma unroll
+            for (int sh = 0; sh < 5; ++sh) {
+                if constexpr ((FB_ABL & 2) != 0) { u32x4 z = {0x3c003c00u, (unsigned)lane, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(z)); wh[sh] = wl[sh] = __builtin_bit_cast(h8, z); continue; }
+                const int tap = along_x ? la * 5 + sh : sh * 5 + la;                 // (wave uniform)
+                wh[sh] = *reinterpret_cast<const h8*>(fc + tap * 2048);
+                wl[sh] = *reinterpret_cast<const h8*>(fc + tap * 2048 + 1024);
+            }
+            if (corner) {
+#pragma unroll
+                for (int sh = 0; sh < 5; ++sh) {
+                    const int yy = y + la - 2, xx = x + sh - 2;
+                    fetch16(img, yy, xx, lk, valid && yy >= 0 && yy < H && xx >= 0 && xx < W, xh[sh], xl[sh]);
+                }
+            } else {
+#pragma unroll
+                for (int sh = 0; sh < 5; ++sh) {
+                    xh[sh] = *reinterpret_cast<const h8*>(win + rd[sh] + la * (20 * 128));
+                    xl[sh] = *reinterpret_cast<const h8*>(win + (rd[sh] ^ 16) + la * (20 * 128));
+                }
+            }
+#pragma unroll
+            for (int sh = 0; sh < 5; ++sh) {
+                if constexpr ((FB_ABL & 8) != 0) { f32x4 t = acc; const h8 a0 = wl[sh], a1 = wh[sh], b0 = xh[sh], b1 = xl[sh]; asm volatile("" : "+v"(t) : "v"(a0), "v"(a1), "v"(b0), "v"(b1)); acc = t; continue; }
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[sh], xh[sh], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[sh], xl[sh], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[sh], xh[sh], acc, 0, 0, 0);
+            }
+        }
+    }
+    if (!valid) return;
+    // lane (lj, lk): phases 4 lk .. 4 lk + 3 of its pixel
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + v * 16 + 4 * lk);
+    const f32x4 o4 = acc * a.inv_scale + bv;
+    const float zero = opaque_zero();
+    const float chk = nonfinite_acc(0.0f, acc, zero);
+    const int orow = W * ps;
+    float* yout = a.out0.ptr;
+    if (ps == 4) {                                             // phases 4 lk .. 4 lk + 3 = HR row 4 y + lk, columns 4 x .. 4 x + 3: one 16-byte store
+        const size_t idx = ((size_t)(img * H + y) * 4 + lk) * orow + (size_t)x * 4;
+        f32x4 o = o4;
+        if constexpr ((FB_ABL & 4) != 0) { if (o.x == 1.2345e-30f) *reinterpret_cast<f32x4*>(yout + idx) = o; } else {
+        if (a.res) o = o + *reinterpret_cast<const f32x4*>(a.res + idx);
+        *reinterpret_cast<f32x4*>(yout + idx) = o;
+        }
+    } else {
+        const float vr[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = 4 * lk + r;
+            if (p < ps * ps) {
+                const int pa = p / ps, pb = p - pa * ps;
+                const size_t idx = ((size_t)(img * H + y) * ps + pa) * orow + (size_t)(x * ps + pb);
+                float out = vr[r];
+                if constexpr ((FB_ABL & 4) != 0) { if (out == 1.2345e-30f) yout[idx] = out; continue; }
+                if (a.res) out += a.res[idx];
+                yout[idx] = out;
+            }
+        }
+    }
+    if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + img] = 1; }
 }
 
 }  // namespace dcscn

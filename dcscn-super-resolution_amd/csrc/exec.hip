@@ -74,7 +74,7 @@ static P16Desc p16_desc(const dcscn_ctx* h, int id) {
 }
 
 bool op_on_split16(const dcscn_ctx* h, const Op& op) {
-    if (op.kind == OP_STREAM || op.kind == OP_TAIL || op.kind == OP_STREAM3) return h->split16 && op.h16.on && (h->split16_mask & 1);      // the F16 instantiation of the streamed kernels
+    if (op.kind == OP_STREAM || op.kind == OP_TAIL || op.kind == OP_STREAM3 || op.kind == OP_FOLDX) return h->split16 && op.h16.on && (h->split16_mask & 1);      // the F16 instantiation of the streamed kernels
     return op.kind == OP_CONV && h->split16 && op.h16.on && (h->split16_mask & (op.shape.nin ? 2 : 1));
 }
 
@@ -142,6 +142,43 @@ int launch_op(dcscn_ctx* h, const Op& op, int nb, int H, int W, const float* x, 
         for (size_t i = 0; i < op.extra_out.size(); ++i) a.out[i] = out_desc(op.extra_out[i], 0, -1);
         a.redo = redo_flags;
         HIP_TRY(h, stream3_launch(a, grid, stream));
+        return DCSCN_OK;
+    }
+    if (op.kind == OP_FOLDX) {
+        if (!stream16) {
+            // split16 = 0, or the float32 plan of a flagged image: the launches the fold replaces (graph.hip: fold_whole_tail)
+            for (const Op& sub : op.fused) {
+                const int rc = launch_op(h, sub, nb, H, W, x, x2, y, stream, redo);
+                if (rc) return rc;
+            }
+            return DCSCN_OK;
+        }
+        ConvArgs b{};
+        b.in = buf_ptr(h, op.in_buf);
+        b.in_stride = h->bufs[op.in_buf].stride;
+        b.in_off = op.in_off;
+        b.cin_phys = op.cin_phys;
+        if (h->p16_now && op.h16.in16_ok) {
+            b.in16 = p16_desc(h, op.in_buf);
+            b.in = nullptr;
+        }
+        b.n_chunks = op.h16.n_chunks;
+        b.wpack16 = op.h16.d_w;                                  // [16 variants][chunk][25 taps][hi | lo]: variant 0 = the interior kernels
+        b.bias = op.h16.d_bias;                                  // [16 variants][16 phases]
+        b.inv_scale = op.h16.inv_scale;
+        b.act = ACT_NONE;
+        b.N = nb; b.H = H; b.W = W;
+        b.tiles_x = (W + 15) / 16;
+        b.tiles_y = (H + 15) / 16;
+        b.out0.ptr = y; b.out0.stride = 1; b.out0.width = 1;
+        b.out1 = b.out0;
+        b.split = 1 << 30;
+        b.ps = op.fold_s; b.ps_c = 1;
+        b.res = x2; b.res_stride = 1;
+        b.fold = 2;
+        b.redo = redo_flags;
+        HIP_TRY(h, c5h_launch(1, b, stream));
+        HIP_TRY(h, c5h_border_launch(b, stream));
         return DCSCN_OK;
     }
     if (op.kind == OP_TAIL) {

@@ -542,6 +542,63 @@ bool fold_linear_tail(dcscn_ctx* h) {
     return true;
 }
 
+// ---- the WHOLE linear tail as one conv (x3, x4; r06) ------------------------------------------------------
+// build_pixel_shuffler_layer is called with activator = None for EVERY stage (tf_graph.py:238-249, DCSCN.py:300-311: no activator argument), so at x4
+// the chain  Up-PS conv + bias -> depth_to_space(2) -> Up-PS2 conv + bias -> depth_to_space(2) -> R-CNN1  is one affine map, as the one-stage x3
+// chain is, dense or depthwise separable (a separable conv is the dense conv  w[t][ci][co] = dw[t][ci] pw[ci][co]).  HR pixel (S y + a, S x + b)
+// is a 5x5 conv of the LR neighbourhood of (y, x) with a kernel per sub-pixel phase (a, b): S^2 <= 16 phases = ONE 16-channel tile on
+// conv5_h.  The zero padding of the intermediate maps (which the reference applies to the SHUFFLED maps, not to the LR one) only acts on the
+// first / last row and column of the image: there the kernel is another one per (vy, vx) in {interior, first, last, both}^2, and instead of
+// computing every variant for every pixel (fold_linear_tail: 4 variants per phase as extra channels -- 36 / 64 channels at x3 / x4, more with
+// two stages) the border ring is a launch of its own (conv5_h.hpp: fold_border), 8 % of a 48 x 48 patch.  pack.hip: pack_foldx composes the
+// kernels in float64.  Replaces [Up-PS, folded Up-PS2 + R-CNN1] (x4), [Up-PS, R-CNN1] (x3), tail_stream (separable x4); those launches stay
+// in `fused` as the float32 plan of a flagged image and the split16 = 0 path.  Option "fold_whole_tail" (0: the r05 plans).
+bool fold_whole_tail(dcscn_ctx* h) {
+    const dcscn_config& c = h->cfg;
+    if (!h->fold_tail || !h->fold_whole || !h->split16 || !(h->split16_mask & 1)) return false;
+    if (!c.pixel_shuffler || c.cnn_size != 3 || c.reconstruct_layers > 1 || (c.scale != 3 && c.scale != 4)) return false;
+    size_t i0 = h->ops.size();
+    for (size_t i = 0; i < h->ops.size(); ++i)
+        if (h->ops[i].name.rfind("Up-PS", 0) == 0) { i0 = i; break; }
+    if (i0 >= h->ops.size()) return false;
+    const Op first = h->ops[i0].kind == OP_TAIL ? h->ops[i0].fused[0] : h->ops[i0];
+    if (first.kind != OP_CONV || first.in_buf < 0 || first.res != 1 || first.act != ACT_NONE || first.tconv_s != 0 || first.segs.size() != 1 ||
+        first.in_stride_override > 0 || !first.multi.empty()) return false;
+    int64_t macs = 0;
+    for (size_t i = i0; i < h->ops.size(); ++i) {
+        const Op& o = h->ops[i];
+        if ((o.kind != OP_CONV && o.kind != OP_COUT1 && o.kind != OP_TAIL) || o.act != ACT_NONE) return false;
+        for (size_t k = 0; k < i0; ++k)                        // nothing in front of the tail reads what it writes
+            if (o.out_buf[0] >= 0 && h->ops[k].in_buf == o.out_buf[0]) return false;
+        macs += o.macs;
+    }
+    const Op& last = h->ops.back();
+    if (last.out_buf[0] != EXT_Y || !last.residual) return false;
+    Op f;
+    f.kind = OP_FOLDX;
+    f.name = "Up-PS.." + std::string(c.reconstruct_layers > 1 ? "R-CNN" : "R-CNN1") + " (folded)";
+    f.ks = 5;
+    f.cin = first.cin;
+    f.cout = c.scale * c.scale;
+    f.res = 1;
+    f.act = ACT_NONE;
+    f.in_buf = first.in_buf; f.in_off = first.in_off; f.cin_phys = first.cin_phys;
+    f.chan_map = first.chan_map;
+    f.fold_s = c.scale;
+    f.ps = c.scale; f.ps_c = 1;
+    f.out_buf[0] = f.out_buf[1] = EXT_Y;
+    f.out_width[0] = 1;
+    f.residual = true;
+    f.vec4 = false;
+    f.halo = 2;
+    f.macs = macs;
+    f.bytes = 4 * (int64_t)first.cin_phys + 8 * (int64_t)c.scale * c.scale;
+    f.fused.assign(h->ops.begin() + i0, h->ops.end());
+    h->ops.erase(h->ops.begin() + i0, h->ops.end());
+    h->ops.push_back(f);
+    return true;
+}
+
 // ---- row-streamed feature extractor (feat_stream.hpp) ---------------------------------------------------
 // Channel that lane group q (= lane >> 4) feeds into k-step s of 16-channel chunk ch, for an input ring of `quads` channel
 // quads (feat_stream.hpp: StreamChunk); -1 = none (the filter row stays zero).
@@ -814,7 +871,7 @@ void plan_p16(dcscn_ctx* h) {
         return v;
     };
     auto can_read = [&](const Op& op) {
-        if (op.kind != OP_CONV || !op.h16.on || op.dwk != 0 || op.in_stride_override > 0) return false;
+        if ((op.kind != OP_CONV && op.kind != OP_FOLDX) || !op.h16.on || op.dwk != 0 || op.in_stride_override > 0) return false;
         if (!op.multi.empty()) return op.shape.nin != 0;          // (the pad-8 virtual K axis of densify_features)
         if (op.in_buf < 0 || op.in_off != 0 || op.cin_phys != h->bufs[op.in_buf].stride) return false;
         for (size_t i = 0; i < op.chan_map.size(); ++i)
@@ -871,7 +928,7 @@ void plan_p16(dcscn_ctx* h) {
     // the float32 plan of a flagged image (exec.hip: run_forward): every launch downstream of a split16 launch or of a P16 tensor
     std::vector<char> dirty(nbuf, 0);
     for (Op& op : h->ops) {
-        bool r = (op.kind == OP_CONV || op.kind == OP_STREAM || op.kind == OP_TAIL || op.kind == OP_STREAM3) && op.h16.on;
+        bool r = (op.kind == OP_CONV || op.kind == OP_STREAM || op.kind == OP_TAIL || op.kind == OP_STREAM3 || op.kind == OP_FOLDX) && op.h16.on;
         for (int b : inputs(op)) r = r || dirty[b];
         for (int k = 0; k < 2; ++k)
             if (op.out_buf[k] >= 0 && !(k == 1 && op.split >= (1 << 29))) r = r || h->bufs[op.out_buf[k]].p16_ok;

@@ -76,6 +76,8 @@ struct ConvArgs {
     // x 4 border variants of the composite [pixel-shuffler conv -> depth_to_space -> 3x3 conv to 1 channel];
     // conv channel v = phase * 4 + variant.  The epilogue picks the variant of each phase from the pixel's
     // position and stores one value per HR pixel into out0 (stride 1), plus `res`.
+    // fold == 2 (graph.hip: fold_whole_tail): conv channel = sub-pixel phase of the WHOLE tail (ps = total scale, ps^2 <= 16: one tile); the launch
+    // stores the pixels that are NOT on the image's border ring with the interior kernel, c5h_border_launch computes the ring.
     int32_t fold;
     const void* srctab;       // conv_nin, multi-source input: device array of NinSrcQuad, 4 * n_chunks entries (nullptr: `in` is one tensor)
     // split16 kernels (split16.hpp: f32-accurate contraction on the f16 matrix pipe)
@@ -152,6 +154,10 @@ hipError_t c3e_launch(int nt, const ConvArgs& a, int n_groups, int n_cus, hipStr
 // fold launch plus args.wpack16 = pack_conv16 image with 25 taps, args.n_chunks = ceil(cin_phys / 32), args.inv_scale, args.redo
 hipError_t c5h_init_kernels();
 hipError_t c5h_launch(int nt, const ConvArgs& args, hipStream_t stream);
+// the border ring of a fold == 2 launch (conv5_h.hpp: fold_border): args.wpack16 = 16 pack_conv16 images [variant = 4 vy + vx][chunk][25 taps][hi | lo],
+// args.bias = [16 variants][16 phases]; vy / vx: 0 interior, 1 first row / column, 2 last, 3 both (a one-pixel axis)
+constexpr int kFoldVariants = 16;
+hipError_t c5h_border_launch(const ConvArgs& args, hipStream_t stream);
 
 // ---- row-streamed feature extractor of the separable narrow nets (feat_stream.hpp) ----
 constexpr int kStreamPX = 48;                  // computed columns per strip: three 16-pixel MFMA tiles

@@ -55,7 +55,205 @@ static int pack_conv3_h16(dcscn_ctx* h, Op& op, const TensorSpec& tw, int wcols,
     return rc;
 }
 
+// ---- fold_whole_tail (graph.hip): the composite 5x5 kernels of the whole tail, one set per border-position class -------------------------
+namespace {
+struct FoldStage {                  // one pixel-shuffler stage as a dense 3x3 conv: w [9][cin][s * s * c], b [s * s * c]
+    int s = 1, cin = 0, c = 0;
+    std::vector<double> w, b;
+};
+
+// the dense equivalent [9][cin][cout] of the 3x3 conv variable `var` (tf_graph.py build_conv / build_depthwise_separable_conv:
+// tf.nn.separable_conv2d with channel_multiplier 1 is the dense conv w[t][ci][co] = depthwise[t][ci] * pointwise[ci][co])
+bool foldx_dense(const dcscn_ctx* h, const std::string& var, int cin, int cout, bool bias, std::vector<double>& w, std::vector<double>& b) {
+    auto find = [&](const std::string& n) -> const TensorSpec* {
+        auto it = h->tensor_index.find(n);
+        return it == h->tensor_index.end() ? nullptr : &h->tensors[it->second];
+    };
+    w.assign((size_t)9 * cin * cout, 0.0);
+    b.assign(cout, 0.0);
+    if (const TensorSpec* t = find(var + "/conv_W")) {
+        if (t->data.size() != w.size()) return false;
+        for (size_t i = 0; i < w.size(); ++i) w[i] = t->data[i];
+    } else {
+        const TensorSpec* dw = find(var + "/depthwise_W");
+        const TensorSpec* pw = find(var + "/pointwise_W");
+        if (!dw || !pw || dw->data.size() != (size_t)9 * cin || pw->data.size() != (size_t)cin * cout) return false;
+        for (int t = 0; t < 9; ++t)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int co = 0; co < cout; ++co) w[((size_t)t * cin + ci) * cout + co] = (double)dw->data[(size_t)t * cin + ci] * (double)pw->data[(size_t)ci * cout + co];
+    }
+    if (bias) {
+        const TensorSpec* bt = find(var + "/conv_B");
+        if (!bt || bt->data.size() != (size_t)cout) return false;
+        for (int co = 0; co < cout; ++co) b[co] = bt->data[co];
+    }
+    return true;
+}
+
+// position classes of a pixel along one axis: 0 interior, 1 first row, 2 last row, 3 both (a one-pixel axis) -- as (size of a virtual image, the
+// pixel's coordinate in it).  The padding of the intermediate maps reaches one LR pixel deep, the composite's support two: 5 / 3 / 3 / 1 pixels.
+const int kFoldHv[4] = {5, 3, 3, 1}, kFoldYv[4] = {2, 0, 2, 0};
+
+// Which (last-conv tap, stage taps ...) chains of HR row S y + a survive the zero padding of the intermediate maps, with the LR offset each
+// ends at: two position classes with the same list have the same kernel (the LR map's own padding multiplies taps by zero: not part of it)
+std::vector<int> foldx_axis_sig(const std::vector<FoldStage>& up, int S, int a, int variant) {
+    const int Hv = kFoldHv[variant], y = kFoldYv[variant];
+    std::vector<std::pair<int, int>> cur, nxt;       // (position, path code)
+    for (int e = -1; e <= 1; ++e) {
+        const int Y = S * y + a + e;
+        if (Y >= 0 && Y < S * Hv) cur.push_back({Y, e + 1});
+    }
+    int res = S;
+    for (int k = (int)up.size() - 1; k >= 0; --k) {
+        res /= up[k].s;
+        nxt.clear();
+        for (const auto& p : cur)
+            for (int f = -1; f <= 1; ++f) {
+                const int q = p.first / up[k].s + f;
+                if (k > 0 && (q < 0 || q >= res * Hv)) continue;
+                nxt.push_back({q, p.second * 3 + f + 1});
+            }
+        cur.swap(nxt);
+    }
+    std::vector<int> sig;
+    for (const auto& p : cur) { sig.push_back(p.second); sig.push_back(p.first - y); }
+    return sig;
+}
+
+// d y(S y + a, S x + b) / d X(y + dy, x + dx, ci) for a pixel of position class (vy, vx), and the constant term: the adjoint of the chain, from the
+// output pixel back through the last conv, and per stage depth_to_space and the 3x3 conv, dropping every tap that leaves an intermediate map
+void foldx_kernel(const std::vector<FoldStage>& up, const std::vector<double>& r, int S, int a, int b, int vy, int vx, std::vector<double>& kw, double& kb) {
+    const int Hv = kFoldHv[vy], y = kFoldYv[vy], Wv = kFoldHv[vx], x = kFoldYv[vx];
+    const int n = (int)up.size(), c_last = up[n - 1].c;
+    typedef std::map<std::pair<int, int>, std::vector<double>> Adj;
+    Adj g;
+    for (int ey = -1; ey <= 1; ++ey)
+        for (int ex = -1; ex <= 1; ++ex) {
+            const int Y = S * y + a + ey, X = S * x + b + ex;
+            if (Y < 0 || Y >= S * Hv || X < 0 || X >= S * Wv) continue;          // the last conv's SAME padding of the HR map
+            std::vector<double>& v = g[{Y, X}];
+            v.assign(c_last, 0.0);
+            for (int c = 0; c < c_last; ++c) v[c] = r[(size_t)((ey + 1) * 3 + (ex + 1)) * c_last + c];
+        }
+    kb = 0.0;
+    int res = S;
+    for (int k = n - 1; k >= 0; --k) {
+        const FoldStage& st = up[k];
+        const int s = st.s, co = s * s * st.c;
+        res /= s;                                    // resolution of the stage's input map
+        Adj gp;
+        for (const auto& kv : g) {
+            const int Y = kv.first.first, X = kv.first.second;
+            const int py = Y / s, px = X / s;
+            const int ch0 = ((Y - py * s) * s + (X - px * s)) * st.c;            // depth_to_space: conv channel of (sub-pixel, c)
+            const std::vector<double>& gv = kv.second;
+            for (int c = 0; c < st.c; ++c) kb += gv[c] * st.b[ch0 + c];
+            for (int fy = -1; fy <= 1; ++fy)
+                for (int fx = -1; fx <= 1; ++fx) {
+                    const int qy = py + fy, qx = px + fx;
+                    if (k > 0 && (qy < 0 || qy >= res * Hv || qx < 0 || qx >= res * Wv)) continue;     // SAME padding of an intermediate map
+                    std::vector<double>& d = gp[{qy, qx}];
+                    if (d.empty()) d.assign(st.cin, 0.0);
+                    const double* wt = &st.w[(size_t)((fy + 1) * 3 + (fx + 1)) * st.cin * co];
+                    for (int ci = 0; ci < st.cin; ++ci) {
+                        const double* wr = wt + (size_t)ci * co + ch0;
+                        double sum = 0.0;
+                        for (int c = 0; c < st.c; ++c) sum += gv[c] * wr[c];
+                        d[ci] += sum;
+                    }
+                }
+        }
+        g.swap(gp);
+    }
+    const int cin0 = up[0].cin;
+    kw.assign((size_t)25 * cin0, 0.0);
+    for (const auto& kv : g) {
+        const int dy = kv.first.first - y, dx = kv.first.second - x;
+        if (dy < -2 || dy > 2 || dx < -2 || dx > 2) continue;                    // (cannot happen: the chain's support is 5 x 5)
+        for (int ci = 0; ci < cin0; ++ci) kw[(size_t)((dy + 2) * 5 + (dx + 2)) * cin0 + ci] = kv.second[ci];
+    }
+}
+}  // namespace
+
+int pack_foldx(dcscn_ctx* h, Op& op) {
+    for (Op& sub : op.fused) {                       // the launches it replaces: the float32 plan of a flagged image, and split16 = 0
+        const int rc = finalize_op(h, sub);
+        if (rc) return rc;
+    }
+    const dcscn_config& c = h->cfg;
+    const int S = op.fold_s, cin = (int)op.chan_map.size();
+    const int ps_out = c.pixel_shuffler_filters != 0 ? c.pixel_shuffler_filters : cin;
+    std::vector<FoldStage> up;
+    if (S == 4) {
+        up.resize(2);
+        up[0].s = 2; up[0].cin = cin; up[0].c = cin;
+        up[1].s = 2; up[1].cin = cin; up[1].c = ps_out;
+    } else {
+        up.resize(1);
+        up[0].s = S; up[0].cin = cin; up[0].c = ps_out;
+    }
+    const char* names[2] = {"Up-PS/Up-PS_CNN", "Up-PS2/Up-PS2_CNN"};
+    for (size_t k = 0; k < up.size(); ++k)
+        if (!foldx_dense(h, names[k], up[k].cin, up[k].s * up[k].s * up[k].c, true, up[k].w, up[k].b))
+            return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: fold_whole_tail does not find the variables of %s", names[k]);
+    std::vector<double> r, r_b;
+    if (!foldx_dense(h, "R-CNN1", ps_out, 1, false, r, r_b)) return fail(h, DCSCN_ERR_UNSUPPORTED, "internal: fold_whole_tail does not find the variables of R-CNN1");
+    // position classes along an axis that share a kernel for phase a (the first class with the same surviving chains)
+    int eff[4][4];
+    for (int a = 0; a < S; ++a) {
+        std::vector<int> sig[4];
+        for (int v = 0; v < 4; ++v) {
+            sig[v] = foldx_axis_sig(up, S, a, v);
+            eff[a][v] = v;
+            for (int u = 0; u < v; ++u)
+                if (sig[u] == sig[v]) { eff[a][v] = u; break; }
+        }
+    }
+    std::map<std::vector<int>, std::pair<std::vector<double>, double>> memo;
+    const int ncols = 16;
+    std::vector<std::vector<float>> dense(kFoldVariants, std::vector<float>((size_t)25 * op.cin_phys * ncols, 0.0f));
+    std::vector<float> b16((size_t)kFoldVariants * ncols, 0.0f);
+    for (int vy = 0; vy < 4; ++vy)
+        for (int vx = 0; vx < 4; ++vx)
+            for (int a = 0; a < S; ++a)
+                for (int b = 0; b < S; ++b) {
+                    const std::vector<int> key = {a, eff[a][vy], b, eff[b][vx]};
+                    auto it = memo.find(key);
+                    if (it == memo.end()) {
+                        std::pair<std::vector<double>, double> kk;
+                        foldx_kernel(up, r, S, a, b, eff[a][vy], eff[b][vx], kk.first, kk.second);
+                        it = memo.emplace(key, std::move(kk)).first;
+                    }
+                    const int v = vy * 4 + vx, p = a * S + b;
+                    const std::vector<double>& kw = it->second.first;
+                    for (int t = 0; t < 25; ++t)
+                        for (int ci = 0; ci < cin; ++ci) dense[v][((size_t)t * op.cin_phys + op.chan_map[ci]) * ncols + p] = (float)kw[(size_t)t * cin + ci];
+                    b16[(size_t)v * ncols + p] = (float)it->second.second;
+                }
+    Op::Split16& s16 = op.h16;
+    s16.nt = 1; s16.n_tiles = 1; s16.n_full = 1;
+    s16.n_chunks = (op.cin_phys + kC3hKC - 1) / kC3hKC;
+    int e = 0;
+    {
+        float m = 0.0f;
+        for (const auto& d : dense)
+            for (float w : d) m = std::fmax(m, std::fabs(w));
+        e = split16_scale_exp(&m, 1);
+    }
+    s16.inv_scale = std::ldexp(1.0f, -e);
+    std::vector<uint16_t> img;
+    for (int v = 0; v < kFoldVariants; ++v) {
+        const std::vector<uint16_t> one = pack_conv16(dense[v], 25, op.cin_phys, ncols, 1, 1, s16.n_chunks, e);
+        img.insert(img.end(), one.begin(), one.end());
+    }
+    int rc = upload(h, img.data(), img.size() * sizeof(uint16_t), &s16.d_w);
+    if (!rc) rc = upload(h, b16.data(), b16.size() * sizeof(float), (void**)&s16.d_bias);
+    s16.on = rc == DCSCN_OK;
+    return rc;
+}
+
 int finalize_op(dcscn_ctx* h, Op& op) {
+    if (op.kind == OP_FOLDX) return pack_foldx(h, op);
     if (op.kind == OP_STREAM3) return pack_feat3_stream(h, op);
     if (op.kind == OP_STREAM) return pack_feat_stream(h, op);
     if (op.kind == OP_TAIL) return pack_tail_stream(h, op);

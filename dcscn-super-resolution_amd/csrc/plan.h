@@ -27,7 +27,7 @@ inline int pad4(int c) { return (c + 3) & ~3; }
 inline int pad16(int c) { return (c + 15) & ~15; }
 
 enum { EXT_X = -1, EXT_X2 = -2, EXT_Y = -3 };
-enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2, OP_COUT1 = 3, OP_STREAM = 4, OP_TAIL = 5, OP_STREAM3 = 6 };
+enum OpKind { OP_CONV = 0, OP_CIN1 = 1, OP_DW = 2, OP_COUT1 = 3, OP_STREAM = 4, OP_TAIL = 5, OP_STREAM3 = 6, OP_FOLDX = 7 };
 
 struct TensorSpec {
     std::string name;
@@ -78,6 +78,7 @@ struct Op {
     int fold_s = 0;                 // > 0: folded linear tail (see fold_linear_tail): pixel-shuffler block
     int fold_c = 0;                 //      channels after depth_to_space
     int fold_rw = -1;               //      filter tensor of the last reconstruction conv [3, 3, C, 1]
+                                    // OP_FOLDX (fold_whole_tail): fold_s = the net's scale; `fused` = the launches it replaces (the float32 plan, split16 = 0)
     // output
     int out_buf[2] = {EXT_Y, EXT_Y}, out_off[2] = {0, 0}, out_width[2] = {0, 0};
     int split = 1 << 30;
@@ -216,6 +217,8 @@ struct dcscn_ctx {
     bool nin = true;                         // wide 1x1 convs on the LDS-DMA staged GEMM (conv_nin); option "nin_gemm" 0 = conv_igemm
     bool fold_force = false;                 // "fold_linear_tail" 2: fold even where the composite does more work than the layers
     bool fold_tail = true;                   // graph rewrite of the linear tail, see fold_linear_tail(); option "fold_linear_tail" 0 = layer by layer
+    bool fold_whole = true;                  // x3 / x4: the WHOLE tail (every shuffler stage + the last conv) as one 5x5 conv of the LR map with per-border-position
+                                             // kernels (fold_whole_tail; option "fold_whole_tail", 0 = the r05 plans)
     bool spatial_tiling = true;              // images larger than one pass are cut into haloed windows (run_tiled)
     std::vector<unsigned long long> h_zrec;  // addresses of the zero records of the P16 planes in the current carve; device copy
     unsigned long long* d_zrec = nullptr;
@@ -253,6 +256,7 @@ bool nin_eligible(const dcscn_ctx* h, const Op& op);
 bool wino_eligible(const dcscn_ctx* h, const Op& op);
 bool h16_direct_eligible(const dcscn_ctx* h, const Op& op);
 bool fold_linear_tail(dcscn_ctx* h);
+bool fold_whole_tail(dcscn_ctx* h);
 int stream_chunk_channel(int quads, int ch, int q, int s);
 bool stream_conv_supported(int in_quads, int out_tiles);
 void fuse_feat_stream(dcscn_ctx* h);
@@ -267,6 +271,7 @@ int finalize_op(dcscn_ctx* h, Op& op);
 int pack_feat_stream(dcscn_ctx* h, Op& op);
 int pack_tail_stream(dcscn_ctx* h, Op& op);
 int pack_feat3_stream(dcscn_ctx* h, Op& op);
+int pack_foldx(dcscn_ctx* h, Op& op);
 // exec.hip
 int ensure_workspace(dcscn_ctx* h, int nb, int H, int W, hipStream_t stream);
 // redo = false: the launch of the pass (split16 kernels where the handle's options allow); true: the op's float32 launch gated by the

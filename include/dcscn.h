@@ -164,6 +164,14 @@ int dcscn_op_info_get(dcscn_handle h, int index, dcscn_op_info* out);
  * channels at x2: the c-DCSCN nets); 2 folds there too.  The work rule is evaluated ONCE, in dcscn_finalize, for the "split16"
  * value in force then (a one-tile composite is cheap on conv5_h and folds; on the f32 kernel it would not): a handle whose
  * split16 option is flipped afterwards keeps the plan it was finalized with.
+ * "fold_whole_tail" (default 1; before dcscn_finalize only; needs fold_linear_tail != 0 and split16 = 1 at finalize): at x3 and x4 EVERY
+ * pixel-shuffler stage is built without an activator (tf_graph.py:238-249 as called from DCSCN.py:300-311), so the whole tail -- Up-PS,
+ * depth_to_space, (Up-PS2, depth_to_space,) the last reconstruction conv, dense or depthwise separable -- is one affine map of the LR tensor:
+ * a 5x5 conv to scale^2 <= 16 sub-pixel phases (ONE channel tile) whose kernel differs only on the first / last row and column of the
+ * image, where the reference zero-pads the SHUFFLED maps.  One launch computes the interior with the interior kernels, a second one the
+ * border ring with the kernels of its 15 (row, column) position classes, all composed in float64 (csrc/pack.hip: pack_foldx); the launches it
+ * replaces -- the shuffler conv(s), the r05 fold of the last stage, tail_stream -- remain the float32 plan of a flagged image and the
+ * split16 = 0 path.  Same function, same parity bars.  0 = the r05 plans.
  * "dense_features" (default 1; before dcscn_finalize only): every feature layer stores into its own dense NHWC buffer and
  * the 1x1 layer(s) that consume tf.concat (DCSCN.py:234) walk the list of buffers, instead of all layers sharing one
  * [n, h, w, sum C_i] tensor -- same bits, full cache lines.  0 = one concat tensor.  Ignored where a consumer of the

@@ -476,26 +476,37 @@ def test_folded_tail_configs(oracle, name):
     assert err <= MAX_ABS_TOL
 
 
-@pytest.mark.parametrize("scale", [2, 3, 4])
+@pytest.mark.parametrize("scale,whole", [(2, 1), (3, 1), (4, 1), (3, 0), (4, 0)])
 @pytest.mark.parametrize("hw", [(1, 1), (1, 6), (7, 1), (2, 2), (3, 5), (16, 16), (17, 33)])
-def test_folded_tail_borders(oracle, scale, hw):
+def test_folded_tail_borders(oracle, scale, whole, hw):
     """The composite kernel changes on the border rows / columns of each sub-pixel phase (the reconstruction conv
     zero-pads the HR map).  Bare network branch (x2 = 0, last conv not scaled down) so that a wrong border
-    variant cannot hide behind the bicubic term; images down to one pixel, where every pixel is a border."""
+    variant cannot hide behind the bicubic term; images down to one pixel, where every pixel is a border.
+    x3 / x4, whole = 1 (the default): the WHOLE tail is one launch of the interior kernels + the border ring's launch (fold_whole_tail);
+    whole = 0: the r05 fold of the last stage, every border variant as extra channels (conv5_h<3> / <1>)."""
+    from dcscn_amd import engine
     cfg = oracle.make_config(layers=3, filters=16, min_filters=8, scale=scale, pixel_shuffler_filters=5)
     weights = oracle.synthetic_weights(cfg, seed=20 + scale)
     weights["R-CNN1/conv_W"] = weights["R-CNN1/conv_W"] * 100.0
     x, _ = synthetic_batch(2, hw[0], hw[1], scale, seed=30)
     x2 = np.zeros((2, hw[0] * scale, hw[1] * scale, 1), np.float32)
     ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
-    with _fold_engine(cfg, weights) as eng:
-        assert len(_folded(eng)) == 1
-        # split16 (default): the composite runs on conv5_h (one / three / four channel tiles for x2 / x3 / x4)
+
+    def fold_engine():
+        eng = engine.Engine(cfg, device=0)
+        eng.set_option("fold_whole_tail", whole)
+        eng.load_weights(weights, fold_tail=True)
+        return eng
+    whole_tail = scale > 2 and whole == 1
+    with fold_engine() as eng:
+        assert _folded(eng) == (["Up-PS..R-CNN1 (folded)"] if whole_tail else [("Up-PS2/Up-PS2_CNN" if scale == 4 else "Up-PS/Up-PS_CNN") + "+R-CNN1 (folded)"])
+        # split16 (default): the composite runs on conv5_h (one channel tile; three for the r05 fold at x3)
         assert [op["kernel"] for op in eng.ops() if "(folded)" in op["name"]] == ["conv5_h"]
         y = eng.forward(x, x2)
-    with _fold_engine(cfg, weights) as eng:
+    with fold_engine() as eng:
         eng.set_option("split16", 0)
-        assert [op["kernel"] for op in eng.ops() if "(folded)" in op["name"]] == ["conv_igemm"]
+        # (the whole-tail fold has no float32 kernel of its own: the launches it replaces run -- also the float32 plan of a flagged image)
+        assert [op["kernel"] for op in eng.ops() if "(folded)" in op["name"]] == ["layer by layer" if whole_tail else "conv_igemm"]
         y32 = eng.forward(x, x2)
     assert float(np.max(np.abs(y32 - ref))) / float(np.max(np.abs(ref))) <= 1e-5
     with _fold_engine(cfg, weights, fold=False) as eng:
@@ -754,25 +765,30 @@ def test_streamed_separable_net_matches_layer_by_layer(oracle, shape):
     x, x2 = synthetic_batch(n, h, w, cfg["scale"], seed=h + w)
     x2 = np.zeros_like(x2)
     outs = {}
-    for mode in (1, 0):
+    # mode 2 = the default plan (r06): feat_stream + the whole tail folded into one 5x5 conv (fold_whole_tail); 1 = the r05 plan, feat_stream +
+    # tail_stream (also the float32 plan behind mode 2); 0 = every layer a launch
+    for mode in (2, 1, 0):
         with engine.Engine(cfg, device=0) as eng:
-            eng.set_option("stream_features", mode)
-            eng.set_option("stream_tail", mode)
+            eng.set_option("stream_features", 1 if mode else 0)
+            eng.set_option("stream_tail", 1 if mode else 0)
+            eng.set_option("fold_whole_tail", 1 if mode == 2 else 0)
             eng.load_weights(weights)
             kernels = [o["kernel"] for o in eng.ops()]
+            assert (kernels == ["feat_stream", "conv5_h"]) == (mode == 2), kernels
             assert (kernels == ["feat_stream", "tail_stream"]) == (mode == 1), kernels
             outs[mode] = eng.forward(x, x2).astype(np.float64)
     scale = np.abs(outs[0]).max()
     assert scale > 1.0
-    err = np.abs(outs[1] - outs[0]).max() / scale
-    print("streamed vs layered, %s: max rel %.3g" % (shape, err))
-    assert err <= 5e-6
-    # ... and both against the float64 oracle (the row-block path of a tall single image and the 3-image batch
+    for mode in (2, 1):
+        err = np.abs(outs[mode] - outs[0]).max() / scale
+        print("%s vs layered, %s: max rel %.3g" % ("folded tail" if mode == 2 else "streamed", shape, err))
+        assert err <= 5e-6
+    # ... and all against the float64 oracle (the row-block path of a tall single image and the 3-image batch
     # met only the layer-by-layer launches before)
     ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
-    for mode in (1, 0):
+    for mode in (2, 1, 0):
         e = np.abs(outs[mode] - ref).max() / np.abs(ref).max()
-        print("  %s vs float64 oracle: max rel %.3g" % ("streamed" if mode else "layered", e))
+        print("  %s vs float64 oracle: max rel %.3g" % (("layered", "streamed", "feat_stream + folded tail")[mode], e))
         assert e <= 5e-6
 
 
