@@ -519,6 +519,70 @@ def test_folded_tail_borders(oracle, scale, whole, hw):
     assert rel <= 1e-5
 
 
+@pytest.mark.parametrize("flags", [
+    dict(scale=3, pixel_shuffler_filters=5),
+    dict(scale=4, pixel_shuffler_filters=1),
+    dict(scale=4, pixel_shuffler_filters=0),                                             # shuffler to all 8 channels: R-CNN1 sums over them
+    dict(scale=4, pixel_shuffler_filters=5, depthwise_separable=True),                   # a separable conv is a dense one: dw[t][c] * pw[c][co]
+    dict(scale=3, pixel_shuffler_filters=1, depthwise_separable=True),
+])
+def test_whole_tail_fold(oracle, flags):
+    """r06: at x3 / x4 every pixel-shuffler stage is built without an activator (tf_graph.py:238-249), so Up-PS (, Up-PS2) and R-CNN1 are ONE
+    5x5 conv of the LR map to scale^2 phases -- the interior on conv5_h, the image's border ring (15 position classes with kernels of their
+    own: the reference zero-pads the SHUFFLED maps) in fold_border.  Bare branch against the float64 oracle on shapes that exercise every job
+    kind: many small images (corner batches of 16), one-pixel axes (the `both` classes), two-pixel axes (no interior), segments past 16 and
+    ragged ends; option fold_whole_tail = 0 (the r05 plan, which is also the float32 plan behind the fold) meets the same bar."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(layers=3, filters=16, min_filters=8, **flags)
+    weights = oracle.synthetic_weights(cfg, seed=41)
+    for k in list(weights):
+        if k.startswith("R-CNN1/") and k.endswith(("conv_W", "pointwise_W")):
+            weights[k] = weights[k] * 100.0
+    s = cfg["scale"]
+    for n, h, w in ((35, 5, 7), (1, 1, 1), (3, 1, 9), (2, 8, 1), (2, 2, 2), (1, 2, 37), (1, 40, 3), (2, 33, 50), (1, 18, 18)):
+        x, _ = synthetic_batch(n, h, w, s, seed=42 + h)
+        x2 = np.zeros((n, h * s, w * s, 1), np.float32)
+        ref = oracle.forward(cfg, weights, x, x2, dtype=np.float64)
+        mag = float(np.max(np.abs(ref)))
+        rel = {}
+        for whole in (1, 0):
+            with engine.Engine(cfg, device=0) as eng:
+                eng.set_option("fold_whole_tail", whole)
+                eng.load_weights(weights)
+                folded = [(o["name"], o["kernel"]) for o in eng.ops() if "(folded)" in o["name"]]
+                assert (("Up-PS..R-CNN1 (folded)", "conv5_h") in folded) == (whole == 1), eng.ops()
+                y = eng.forward(x, x2)
+                assert np.array_equal(y, eng.forward(x, x2))
+            rel[whole] = float(np.max(np.abs(y - ref))) / mag
+        print("%s %dx%dx%d: whole-tail fold rel %.3g, r05 plan %.3g" % (flags, n, h, w, rel[1], rel[0]))
+        assert rel[1] <= 5e-6 and rel[0] <= 5e-6
+
+
+@pytest.mark.parametrize("name", ["L7_F32to8_x4", "L7_F32to8_x4_DS", "L7_F32to8_x3"])
+def test_whole_tail_fold_flagged_image_takes_the_float32_plan(oracle, name):
+    """The folded tail has no float32 kernel of its own: for a flagged image (values beyond the f16 range) the launches it replaces run, gated,
+    behind the pass -- bit-identical to a split16 = 0 run of that image; the bystanders keep their bits; the next forward is clean."""
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS[name])
+    weights = oracle.synthetic_weights(cfg, seed=9)
+    x, x2 = synthetic_batch(3, 21, 50, cfg["scale"], seed=10)
+    xb = x.copy()
+    xb[1] *= 4000.0
+    with engine.Engine(cfg, device=0) as eng:
+        eng.load_weights(weights)
+        assert [o["kernel"] for o in eng.ops()][-1] == "conv5_h" and eng.ops()[-1]["name"] == "Up-PS..R-CNN1 (folded)"
+        clean = eng.forward(x, x2)
+        y = eng.forward(xb, x2)
+        again = eng.forward(x, x2)
+        eng.set_option("split16", 0)
+        assert [o["kernel"] for o in eng.ops()][-1] == "layer by layer"
+        y32 = eng.forward(xb, x2)
+    assert np.isfinite(y).all()
+    assert np.array_equal(y[0], clean[0]) and np.array_equal(y[2], clean[2])
+    assert np.array_equal(y[1], y32[1])
+    assert np.array_equal(again, clean)
+
+
 @pytest.mark.parametrize("variant", [
     dict(layers=3, filters=16, min_filters=8, depthwise_separable=True),                 # separable convs
     dict(layers=3, filters=16, min_filters=8, pixel_shuffler=False),                     # transposed-conv upsampler
