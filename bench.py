@@ -57,7 +57,13 @@ def _kernel_family(name):
     """Kernel family of a profiler kernel name ('void dcscn::conv3_h8<6, 5, ...>(...)' / 'conv3_h8<6,5,0,6,true>') or of a
     dcscn_op_info kernel: the bare identifier in front of the template arguments."""
     n = name.split("(")[0].split("<")[0].strip()
-    return n.split("::")[-1].split(" ")[-1]
+    n = n.split("::")[-1].split(" ")[-1]
+    return KERNEL_ALIASES.get(n, n)
+
+
+# launches that dcscn_op_info reports under another kernel's name: the border ring of a whole-tail fold (csrc/conv5_h.hpp: fold_border)
+# is the second launch of its conv5_h op
+KERNEL_ALIASES = {"fold_border": "conv5_h"}
 
 
 def _pmc_file(prefix, run_kernels=None):
@@ -324,8 +330,9 @@ def time_other_config(engine, O, torch, key, steps, warmup, device_index, stream
             if tr:
                 detail["compulsory_bytes_per_step"] = io * px
                 detail["traffic_ratio"] = round(tr / (io * px), 3)
-                detail["note"] = ("two launches: Concat2 (32 channels, 128 B per LR pixel) is written by feat_stream and read by tail_stream -- "
-                                  "the counters see exactly x + Concat2 and Concat2 + x2 + y")
+                detail["note"] = ("launches %s: Concat2 (32 channels, 128 B per LR pixel) is written by the feature launch and read by the tail's "
+                                  "(r06: the whole tail folded into one 5x5 conv, conv5_h + the border ring's fold_border) -- the counters see "
+                                  "x + Concat2 and Concat2 (+ the ring's windows) + x2 + y" % "+".join(o["kernel"] for o in ops))
         return out
     finally:
         eng.close()

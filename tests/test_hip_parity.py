@@ -646,12 +646,16 @@ def test_spatial_tiling_window_too_small(oracle):
 
 
 class _Hip:
-    """The few HIP runtime calls the device-pointer test needs, through ctypes (the runtime the library itself loaded)."""
+    """The few HIP runtime calls the device-pointer test needs, through ctypes -- resolved through libdcscn_hip.so's own handle, i.e. in the
+    runtime the library is linked to.  (dlopen("libamdhip64.so") is NOT that runtime once torch has been imported in the process -- the
+    full-size parity tests above do, for the float64 restatement -- but the copy bundled with the torch wheel: a second, uninitialised HIP
+    runtime whose first call fails with hipErrorNoDevice.  r06: the serial suite failed exactly so.)"""
 
     def __init__(self):
         import ctypes
+        from dcscn_amd import engine
         self.c = ctypes
-        self.lib = ctypes.CDLL("libamdhip64.so")
+        self.lib = ctypes.CDLL(engine.library_path())          # dlsym on this handle searches the library's dependencies: ITS libamdhip64
         self.lib.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
         self.lib.hipFree.argtypes = [ctypes.c_void_p]
         self.lib.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
