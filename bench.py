@@ -810,7 +810,9 @@ def main():
                 except Exception as exc:
                     result["other_configs"][key] = {"error": str(exc)}
             try:
-                result["parity"] = parity_leg()
+                import contextlib
+                with contextlib.redirect_stdout(sys.stderr):      # (the model prints like the reference's: stdout carries the ONE JSON line only)
+                    result["parity"] = parity_leg()
             except Exception as exc:
                 result["parity"] = {"error": str(exc)}
         print(json.dumps(result), flush=True)
