@@ -63,7 +63,7 @@ def _kernel_family(name):
 
 # launches that dcscn_op_info reports under another kernel's name: the border ring of a whole-tail fold (csrc/conv5_h.hpp: fold_border)
 # is the second launch of its conv5_h op
-KERNEL_ALIASES = {"fold_border": "conv5_h"}
+KERNEL_ALIASES = {"fold_border": "conv5_h", "conv_nin_h_w8": "conv_nin_h"}      # (conv_nin_h_w8: the 256-pixel workgroups of the wide K axes)
 
 
 def _pmc_file(prefix, run_kernels=None):

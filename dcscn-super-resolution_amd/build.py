@@ -15,7 +15,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_NAME = "libdcscn_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
-SOURCES = ["api.hip", "graph.hip", "pack.hip", "exec.hip", "kernels.hip", "resample.hip", "ensemble.hip", "color.hip", "conv_k1.hip", "conv_k3.hip", "conv_k5.hip", "conv_k7.hip", "conv_wino2.hip", "conv_nin.hip", "feat_stream.hip", "conv_nin_h.hip", "conv3_h.hip", "conv3_h8.hip", "conv5_h.hip", "conv3_h_p16.hip", "conv3_h8_p16.hip", "feat_stream_redo.hip", "feat3_stream.hip"]
+SOURCES = ["api.hip", "graph.hip", "pack.hip", "exec.hip", "kernels.hip", "resample.hip", "ensemble.hip", "color.hip", "conv_k1.hip", "conv_k3.hip", "conv_k5.hip", "conv_k7.hip", "conv_wino2.hip", "conv_nin.hip", "feat_stream.hip", "conv_nin_h.hip", "conv_nin_h_w8.hip", "conv3_h.hip", "conv3_h8.hip", "conv5_h.hip", "conv3_h_p16.hip", "conv3_h8_p16.hip", "feat_stream_redo.hip", "feat3_stream.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "plan.h", "conv_igemm.hpp", "conv_wino2.hpp", "conv_nin.hpp", "conv_variants.hpp", "feat_stream.hpp", "tail_stream.hpp", "feat3_stream.hpp",
                                               "split16.hpp", "split16_pack.hpp", "p16.hpp", "conv_nin_h.hpp", "conv3_h.hpp", "conv3_h8.hpp", "conv5_h.hpp")] + \
           [os.path.join(INCLUDE, "dcscn.h")]
@@ -29,10 +29,10 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 # per-source extra flags (see the comment at the top of conv_wino2.hip)
 EXTRA_FLAGS = {"conv_wino2.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"],
                "conv_nin.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"],
-               "conv_nin_h.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv3_h.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv3_h8.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv3_h_p16.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv3_h8_p16.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv5_h.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "color.hip": ["-ffp-contract=off"], "feat_stream.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "feat_stream_redo.hip": ["-fno-slp-vectorize"], "feat3_stream.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"]}
+               "conv_nin_h.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv_nin_h_w8.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv3_h.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv3_h8.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv3_h_p16.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv3_h8_p16.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "conv5_h.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "color.hip": ["-ffp-contract=off"], "feat_stream.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"], "feat_stream_redo.hip": ["-fno-slp-vectorize"], "feat3_stream.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"]}
 # kernels that sit at the VGPR limit by design (192 accumulators + operands): a register spill inside their K loop also
 # breaks the hand-counted vmcnt accounting of the LDS-DMA pipeline, so a build that spills is rejected, not shipped
-NO_SCRATCH = ("conv_wino2.hip", "conv_nin.hip", "feat_stream.hip", "conv_nin_h.hip", "conv3_h.hip", "conv3_h8.hip", "conv5_h.hip", "conv3_h_p16.hip", "conv3_h8_p16.hip", "feat3_stream.hip")
+NO_SCRATCH = ("conv_wino2.hip", "conv_nin.hip", "feat_stream.hip", "conv_nin_h.hip", "conv_nin_h_w8.hip", "conv_nin_h_w8.hip", "conv3_h.hip", "conv3_h8.hip", "conv5_h.hip", "conv3_h_p16.hip", "conv3_h8_p16.hip", "feat3_stream.hip")
 
 
 def hipcc_path():

@@ -1,4 +1,6 @@
 // conv_nin_h variants (conv_nin_h.hpp), one translation unit to parallelise the build.
+#include <cstdlib>
+
 #include "conv_nin_h.hpp"
 
 namespace dcscn {
@@ -18,8 +20,14 @@ static hipError_t nin_h_set_attr() {
                                NinHGeom<NT, kNinHStages>::LDS_BYTES + kNinHMaxTable);
 }
 
+hipError_t nin_h8_init_kernels();                                // conv_nin_h_w8.hip: 256 pixels per workgroup, for the wide K axes
+hipError_t nin_h8_launch(const ConvArgs& a, int n_groups, hipStream_t stream);
+constexpr int kNinH8MinChunks = 32;                             // K >= 1024 channels (-3 % at 1301; slower at 540: profiles/r05_ninh_ablation.txt)
+
 hipError_t nin_h_init_kernels() {
-    hipError_t e = nin_h_set_attr<1>();
+    hipError_t e = nin_h8_init_kernels();
+    if (e != hipSuccess) return e;
+    e = nin_h_set_attr<1>();
     if (e == hipSuccess) e = nin_h_set_attr<2>();
     if (e == hipSuccess) e = nin_h_set_attr<3>();
     if (e == hipSuccess) e = nin_h_set_attr<4>();
@@ -48,6 +56,8 @@ static hipError_t nin_h_launch_one(const ConvArgs& a, int n_groups, hipStream_t 
 
 hipError_t nin_h_launch(int nt, const ConvArgs& a, int n_groups, hipStream_t stream) {
     if (a.n_full < 1 || a.n_full > n_groups || (nt == 1 && a.n_full != n_groups) || !a.wpack16) return hipErrorInvalidValue;
+    static const bool w8 = !(getenv("DCSCN_NINH8") && getenv("DCSCN_NINH8")[0] == '0');     // (A/B aid: DCSCN_NINH8=0 keeps the 128-pixel workgroups)
+    if (w8 && nt == 6 && a.in16.base && a.n_chunks >= kNinH8MinChunks && a.n_full == n_groups) return nin_h8_launch(a, n_groups, stream);
     switch (nt) {
         case 1: return nin_h_launch_one<1>(a, n_groups, stream);
         case 2: return nin_h_launch_one<2>(a, n_groups, stream);
