@@ -181,7 +181,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void conv5_h(const ConvArgs a
 
     const int n_chunks = a.n_chunks;
     dma_col(0, 0, 0);
-    load_in(0);
+#ifndef C5H_ABL
+#define C5H_ABL 0          // timing-only builds (results wrong by design): 1 no fetch of the first chunk's image (the prologue a persistent kernel would hide)
+#endif
+    if constexpr ((C5H_ABL & 1) == 0) load_in(0);
+    else static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL { gin[decltype(r_)::value] = f32x4{1.0f, 2.0f, 3.0f, (float)tid}; });
     static_for<0, G::IN_ROUNDS>([&](auto r_) DCSCN_INL { convert_in(r_, 0); });
     store_in();
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
