@@ -24,10 +24,20 @@
 
 #ifndef S3_ABL
 #define S3_ABL 0           // tools/s3_abl.sh: timing-only builds (results wrong by design): 1 no MFMAs, 2 no ring reads, 4 no global stores, 8 no CNN1 arithmetic,
-                           // 16 no epilogue arithmetic (PReLU / split / swap)
+                           // 16 no epilogue arithmetic (PReLU / split / swap), 32 no ring stores, 64 no workgroup barrier, 128 no loads of the input image
 #endif
 
 namespace dcscn {
+
+// (ring stores and the step's barrier through wrappers: the timing-only builds of tools/s3_abl.sh take them out)
+__device__ __forceinline__ void s3_st(unsigned addr, f32x4 v) {
+    if constexpr ((S3_ABL & 32) != 0) asm volatile("" ::"v"(v), "v"(addr));
+    else stream_st(addr, v);
+}
+__device__ __forceinline__ void s3_barrier() {
+    if constexpr ((S3_ABL & 64) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else stream_barrier();
+}
 
 __device__ __forceinline__ StreamArgs s3_geometry(const Stream3Args& a) {
     StreamArgs g{};                                            // stream_row only looks at the job geometry
@@ -93,6 +103,7 @@ __device__ __forceinline__ void s3_first_role(const Stream3Args& a, const Stream
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int cx = ri.sx + 3 * j + k - 1;
+            if constexpr ((S3_ABL & 128) != 0) dst[k] = (float)(cx & 7); else
             dst[k] = live && cx >= 0 && cx < a.W ? row[cx] : 0.0f;
         }
     };
@@ -132,7 +143,7 @@ __device__ __forceinline__ void s3_first_role(const Stream3Args& a, const Stream
                     const u32x4 unit = p16_unit(v, m1, chk, zero2);
                     if (to_global && ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(a.out[0], ro, 3 * j + m, n, q, unit, v);
                     // (four ring slots: row g goes to its slot while CNN2 reads rows g-3 .. g-1; ONE barrier per step)
-                    if (2 * n + (q >> 1) < a.first_out.octs) stream_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, __builtin_bit_cast(f32x4, unit));
+                    if (2 * n + (q >> 1) < a.first_out.octs) s3_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, __builtin_bit_cast(f32x4, unit));
                 }
             }
             if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
@@ -141,7 +152,7 @@ __device__ __forceinline__ void s3_first_role(const Stream3Args& a, const Stream
         const long long tb = __builtin_readcyclecounter();
         dbg_c += tb - dbg_t;
 #endif
-        stream_barrier();
+        s3_barrier();
 #ifdef S3_DBG
         dbg_t = __builtin_readcyclecounter();
         dbg_b += dbg_t - tb;
@@ -298,7 +309,7 @@ __device__ __forceinline__ void s3_conv_step(const Stream3Args& a, const StreamA
         for (int n = 0; n < NT; ++n)
             if (2 * n + (q >> 1) < c.out.octs) {
 #pragma unroll
-                for (int m = 0; m < kStreamMT; ++m) stream_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, zero_row ? kStreamZero : __builtin_bit_cast(f32x4, unit[m][n]));
+                for (int m = 0; m < kStreamMT; ++m) s3_st(wb + (unsigned)m * out_px + (unsigned)n * 64u, zero_row ? kStreamZero : __builtin_bit_cast(f32x4, unit[m][n]));
             }
     }
 }
@@ -317,7 +328,7 @@ __device__ __forceinline__ void s3_conv_role(const Stream3Args& a, const StreamA
         const long long tb = __builtin_readcyclecounter();
         dbg_c += tb - dbg_t;
 #endif
-        stream_barrier();
+        s3_barrier();
 #ifdef S3_DBG
         dbg_t = __builtin_readcyclecounter();
         dbg_b += dbg_t - tb;
@@ -348,7 +359,7 @@ __device__ __forceinline__ void s3_pair_role(const Stream3Args& a, const StreamA
         const long long tb = __builtin_readcyclecounter();
         dbg_c += tb - dbg_t;
 #endif
-        stream_barrier();
+        s3_barrier();
 #ifdef S3_DBG
         dbg_t = __builtin_readcyclecounter();
         dbg_b += dbg_t - tb;
@@ -439,7 +450,7 @@ __device__ __forceinline__ void s3_nin_role(const Stream3Args& a, const StreamAr
                 v = !ri.zero && cx >= 0 && cx < a.W ? v : kStreamZero;      // SAME padding for B2: zero rows and columns outside the image are zeros in the ring
                 const u32x4 unit = p16_unit(v, m1, chk, zero2);
                 if (!ri.zero && ri.store && cx >= ri.ux0 && cx < ri.ux1) s3_store_global(a.out2, ro, 3 * j + m, n, q, unit, v);
-                if (n == 0 && q < 2) stream_st(wb + (unsigned)m * b1_px, __builtin_bit_cast(f32x4, unit));      // B1 = channels 0 .. 7: the octet's hi and lo units
+                if (n == 0 && q < 2) s3_st(wb + (unsigned)m * b1_px, __builtin_bit_cast(f32x4, unit));      // B1 = channels 0 .. 7: the octet's hi and lo units
             }
             if (chk != chk && a.redo) { a.redo[0] = 1; a.redo[1 + ri.img] = 1; }
         }
@@ -447,7 +458,7 @@ __device__ __forceinline__ void s3_nin_role(const Stream3Args& a, const StreamAr
         const long long tb = __builtin_readcyclecounter();
         dbg_c += tb - dbg_t;
 #endif
-        stream_barrier();
+        s3_barrier();
 #ifdef S3_DBG
         dbg_t = __builtin_readcyclecounter();
         dbg_b += dbg_t - tb;

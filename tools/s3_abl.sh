@@ -4,7 +4,7 @@
 #   on the GPU box:          bash tools/s3_abl.sh run        -> one line per build (c-DCSCN x2, 1024 patches)
 cd "$(dirname "$0")/.."
 P=dcscn-super-resolution_amd
-MASKS="0 1 4 31"      # (0 1 2 3 4 8 16 31) + "dbg": the shipped kernel with per-wave shader-clock sums (S3_DBG), printed once
+MASKS="0 31 32 64 63 95 159 255"      # (0 1 2 3 4 8 16 31) + "dbg": the shipped kernel with per-wave shader-clock sums (S3_DBG), printed once
 if [ "$1" = build ]; then
     mkdir -p tools/abl
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Xclang -target-feature -Xclang -packed-fp32-ops -fno-slp-vectorize -DS3_DBG \
