@@ -3,6 +3,8 @@
 Tolerances are the ones BASELINE.json's north_star states: max-abs pixel error <= 1e-4 on the 0-255
 scale against the float64 oracle (the reference itself is float32 TensorFlow).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -993,6 +995,36 @@ def test_p16_overflow_recomputes_the_image_on_the_float32_plan(oracle):
     assert np.array_equal(y[0], clean[0]) and np.array_equal(y[2], clean[2])
     assert np.array_equal(y[1], y32[1])
     assert np.array_equal(again, clean)
+
+
+def test_wide_gemm_workgroup_sizes_give_the_same_bits(oracle):
+    """r06: the 1301-channel A1 || B1 GEMM of the L12 nets runs on 256-pixel workgroups (conv_nin_h_w8: 8 waves x two tiles, half the filter
+    traffic per pixel), every other 1x1 GEMM on 128-pixel ones -- same products in the same order per pixel.  DCSCN_NINH8=0 (read once per
+    process) keeps the 128-pixel workgroups: two subprocesses, one digest; 300 pixels per image so that both sizes have a ragged last block."""
+    import hashlib
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, hashlib, numpy as np\n"
+        "root = %r\n"
+        "sys.path[:0] = [root, os.path.join(root, 'oracle'), os.path.join(root, 'tests')]\n"
+        "import dcscn_oracle as O\n"
+        "from conftest import CONFIGS, synthetic_batch\n"
+        "from dcscn_amd import engine\n"
+        "cfg = O.make_config(**CONFIGS['L12_F196to48_x2'])\n"
+        "w = O.synthetic_weights(cfg, seed=5)\n"
+        "x, x2 = synthetic_batch(3, 20, 15, 2, seed=6)\n"
+        "eng = engine.Engine(cfg, device=0); eng.load_weights(w)\n"
+        "assert 'conv_nin_h' in [o['kernel'] for o in eng.ops()]\n"
+        "print('DIGEST', hashlib.sha256(eng.forward(x, x2).tobytes()).hexdigest())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for flag in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DCSCN_NINH8=flag), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
 
 
 @pytest.mark.parametrize("scale", [2, 3, 4])
