@@ -447,6 +447,35 @@ def test_full_size_c2_workload(oracle):
         assert err <= MAX_ABS_TOL
 
 
+@pytest.mark.parametrize("name,n", [("L7_F32to8_x4_DS", 1024), ("L7_F32to8_x4", 1024), ("L12_F196to48_x4", 64)])
+def test_full_size_x4_workloads(oracle, name, n):
+    """BASELINE.json configs[4] at its full size (L7_F32to8 x4 depthwise separable, 1024 patches of 48x48), the c-DCSCN x4 net at the same size
+    and the L12 x4 graph of configs[3] on 64 patches: EVERY patch against the float64 torch-CPU restatement (pinned to the numpy oracle on
+    three of them) -- through the whole-tail fold (interior launch + 256 corner jobs of 16 images at n = 1024) and, fold_whole_tail = 0,
+    through the r05 plans."""
+    import torch
+    import cpu_path_torch as T
+    from dcscn_amd import engine
+    cfg = oracle.make_config(**CONFIGS[name])
+    weights = oracle.synthetic_weights(cfg, seed=0)
+    rng = np.random.default_rng(13)
+    x = rng.uniform(0, 255, (n, 48, 48, 1)).astype(np.float32)
+    x2 = rng.uniform(0, 255, (n, 192, 192, 1)).astype(np.float32)
+    model = T.TorchCpuModel(cfg, weights, dtype=torch.float64)
+    ref = np.concatenate([model.forward(x[i:i + 128], x2[i:i + 128]) for i in range(0, n, 128)])
+    pick = [0, n // 3, n - 1]
+    assert float(np.max(np.abs(oracle.forward(cfg, weights, x[pick], x2[pick], dtype=np.float64) - ref[pick]))) <= 1e-9
+    for whole in (1, 0):
+        with engine.Engine(cfg, device=0) as eng:
+            eng.set_option("fold_whole_tail", whole)
+            eng.load_weights(weights)
+            assert (eng.ops()[-1]["name"] == "Up-PS..R-CNN1 (folded)") == (whole == 1)
+            y = eng.forward(x, x2)
+        err = np.max(np.abs(y - ref), axis=(1, 2, 3))
+        print("%s, %d patches, fold_whole_tail %d: worst patch %.3g, mean of the maxima %.3g" % (name, n, whole, err.max(), err.mean()))
+        assert float(err.max()) <= MAX_ABS_TOL
+
+
 # ---- opt-in graph rewrite: the linear tail as one 5x5 conv (include/dcscn.h "fold_linear_tail") ----------
 
 def _fold_engine(cfg, weights, fold=True, split16=None):
